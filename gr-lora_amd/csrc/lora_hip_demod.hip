@@ -1,0 +1,321 @@
+// lora_hip_demod.hip -- C ABI (include/lora_hip_demod.h) over the gfx950 kernels.
+// Product code: never links or calls anything under oracle/.
+#include "lora_hip_demod.h"
+#include "lora_hip_kernels.hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using lora_hip::KParams;
+
+struct lora_hip_demod {
+  int device = 0;
+  unsigned sf = 0, fft_factor = 0, n = 0, m = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  float2 *d_up = nullptr, *d_down = nullptr, *d_tw = nullptr;   // d_tw: twc then the pass tables
+  size_t tw_off[3] = {0, 0, 0};
+  float *d_win = nullptr;
+  // staging for host-resident arguments (grown on demand, reused)
+  float2 *d_iq = nullptr; size_t cap_iq = 0;
+  void *d_desc = nullptr; size_t cap_desc = 0;
+  unsigned short *d_idx = nullptr; float *d_val = nullptr; size_t cap_out = 0;
+  char hip_err[256] = {0};
+  const char *kernel_name = "";
+};
+
+namespace {
+
+int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
+  if (h) snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e));
+  return LORA_HIP_EHIP;
+}
+#define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
+
+template <typename T>
+int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
+  if (want <= *cap) return LORA_HIP_OK;
+  if (*buf) { hipError_t e = hipFree(*buf); *buf = nullptr; *cap = 0; if (e != hipSuccess) return hip_fail(h, e, "hipFree"); }
+  size_t ncap = want + want / 4;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(buf), ncap * sizeof(T));
+  if (e != hipSuccess) { *buf = nullptr; hip_fail(h, e, "hipMalloc"); return LORA_HIP_ENOMEM; }
+  *cap = ncap;
+  return LORA_HIP_OK;
+}
+
+typedef void (*kernel_fn)(const KParams);
+struct Variant { kernel_fn fn; size_t lds; int wpb; const char *name; };
+
+template <int LOGN, int F>
+Variant make_variant(const char *name) {
+  return Variant{&lora_hip::demod_kernel<LOGN, F>, lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN>(), name};
+}
+
+#define LORA_VARIANTS_SF(SF) \
+  case SF: \
+    if (f == 1) { *v = make_variant<SF, 1>("demod_kernel<" #SF ",1>"); return true; } \
+    if (f == 2) { *v = make_variant<SF, 2>("demod_kernel<" #SF ",2>"); return true; } \
+    if (f == 4) { *v = make_variant<SF, 4>("demod_kernel<" #SF ",4>"); return true; } \
+    return false;
+
+bool pick_variant(unsigned sf, unsigned f, Variant *v) {
+  switch (sf) {
+    LORA_VARIANTS_SF(6) LORA_VARIANTS_SF(7) LORA_VARIANTS_SF(8) LORA_VARIANTS_SF(9)
+    LORA_VARIANTS_SF(10) LORA_VARIANTS_SF(11) LORA_VARIANTS_SF(12)
+    default: return false;
+  }
+}
+
+int launch(lora_hip_demod *h, KParams &p) {
+  Variant v;
+  if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
+  if (p.n_win == 0) return LORA_HIP_OK;
+  const unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
+  hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+  return LORA_HIP_OK;
+}
+
+// GNU Radio 3.7 gr-fft window.cc Izero(): I0 by power series until the term < 1e-21 * sum
+double izero(double x) {
+  double sum = 1, u = 1, halfx = x / 2.0;
+  int n = 1;
+  do {
+    double temp = halfx / (double)n;
+    n += 1;
+    temp *= temp;
+    u *= temp;
+    sum += u;
+  } while (u >= 1E-21 * sum);
+  return sum;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lora_hip_strerror(int code) {
+  switch (code) {
+    case LORA_HIP_OK: return "ok";
+    case LORA_HIP_EINVAL: return "invalid argument";
+    case LORA_HIP_EUNSUPPORTED: return "unsupported fft_factor (supported: 1, 2, 4)";
+    case LORA_HIP_ENOMEM: return "out of memory";
+    case LORA_HIP_EHIP: return "HIP runtime error";
+    case LORA_HIP_ENODEVICE: return "no usable GPU device";
+    default: return "unknown error";
+  }
+}
+
+const char *lora_hip_last_hip_error(const lora_hip_demod_t *h) { return h ? h->hip_err : ""; }
+
+int lora_hip_make_chirp_tables(unsigned sf, lora_c32 *up, lora_c32 *down) {
+  if (sf < 6 || sf > 12 || !up || !down) return LORA_HIP_EINVAL;
+  const int n = 1 << sf;
+  // lib/demod_impl.cc:92-101: float phase re-rounded every step, double accumulator,
+  // std::polar(1.0, acc) in double, narrowed to complex<float>
+  float phase = -M_PI;
+  double accumulator = 0;
+  for (int i = 0; i < 2 * n; i++) {
+    accumulator += phase;
+    const double c = std::cos(accumulator), s = std::sin(accumulator);
+    down[i].re = (float)c; down[i].im = (float)(-s);
+    up[i].re = (float)c;   up[i].im = (float)s;
+    phase += (2 * M_PI) / n;
+  }
+  return LORA_HIP_OK;
+}
+
+int lora_hip_make_kaiser(unsigned ntaps, double beta, float *w) {
+  if (ntaps < 2 || !w || beta < 0) return LORA_HIP_EINVAL;
+  const double ibeta = 1.0 / izero(beta);
+  const double inm1 = 1.0 / ((double)(ntaps - 1));
+  for (unsigned i = 0; i < ntaps; i++) {
+    double temp = 2 * (int)i * inm1 - 1;
+    w[i] = (float)(izero(beta * std::sqrt(1.0 - temp * temp)) * ibeta);
+  }
+  return LORA_HIP_OK;
+}
+
+int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsigned fft_factor, float beta,
+                          const float *window_n, const lora_c32 *up_2n, const lora_c32 *down_2n) {
+  if (!out) return LORA_HIP_EINVAL;
+  *out = nullptr;
+  if (sf < 6 || sf > 12 || fft_factor == 0) return LORA_HIP_EINVAL;   // asserts at demod_impl.cc:70-72
+  if (fft_factor != 1 && fft_factor != 2 && fft_factor != 4) return LORA_HIP_EUNSUPPORTED;
+  const bool all_null = !window_n && !up_2n && !down_2n;
+  if (!all_null && (!window_n || !up_2n || !down_2n)) return LORA_HIP_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LORA_HIP_ENODEVICE;
+  if (device < 0 || device >= ndev) return LORA_HIP_ENODEVICE;
+
+  lora_hip_demod *h = new (std::nothrow) lora_hip_demod();
+  if (!h) return LORA_HIP_ENOMEM;
+  h->device = device; h->sf = sf; h->fft_factor = fft_factor;
+  h->n = 1u << sf; h->m = h->n * fft_factor;
+  Variant v;
+  pick_variant(sf, fft_factor, &v);
+  h->kernel_name = v.name;
+
+  const size_t n = h->n, m = h->m;
+  std::vector<lora_c32> up(2 * n), down(2 * n);
+  std::vector<float> win(n);
+  if (all_null) {
+    lora_hip_make_chirp_tables(sf, up.data(), down.data());
+    lora_hip_make_kaiser((unsigned)n, beta, win.data());
+  } else {
+    memcpy(up.data(), up_2n, 2 * n * sizeof(lora_c32));
+    memcpy(down.data(), down_2n, 2 * n * sizeof(lora_c32));
+    memcpy(win.data(), window_n, n * sizeof(float));
+  }
+  // Twiddle tables, evaluated in double and rounded once (layouts: lora_hip_kernels.hip.h):
+  //   twc[rr][m]            = W_M^(rr*m*N/R)                       pass-0 input constants
+  //   twp[ps][rr][m-1][jm]  = W_M^(m*(N/L_ps)*(F*jm + rr))         merged pass twiddles, ps >= 1
+  std::vector<lora_c32> tw;
+  auto wm = [&](unsigned long long e) {
+    const double a = -2.0 * M_PI * (double)(e % m) / (double)m;
+    return lora_c32{(float)std::cos(a), (float)std::sin(a)};
+  };
+  const int R = lora_hip::plan_points((int)sf), NP = lora_hip::plan_passes((int)sf);
+  const unsigned F = fft_factor;
+  for (unsigned rr = 0; rr < F; rr++)
+    for (int k = 0; k < R; k++) tw.push_back(wm((unsigned long long)rr * k * (n / R)));
+  {
+    unsigned long long NS = lora_hip::plan_radix((int)sf, 0);
+    for (int ps = 1; ps < NP; ps++) {
+      const unsigned long long r = lora_hip::plan_radix((int)sf, ps), L = NS * r;
+      h->tw_off[ps] = tw.size();
+      for (unsigned rr = 0; rr < F; rr++)
+        for (unsigned long long mm = 1; mm < r; mm++)
+          for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(mm * (n / L) * (F * jm + rr)));
+      NS = L;
+    }
+  }
+
+  int rc = LORA_HIP_OK;
+  auto fail = [&](int code) { lora_hip_demod_destroy(h); return code; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) { return fail(LORA_HIP_EHIP); }
+  if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail(LORA_HIP_EHIP);
+  h->stream = h->own_stream;
+  if (hipMalloc((void **)&h->d_up, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_down, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_win, n * sizeof(float)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  // kernels with more than 64 KiB of dynamic LDS need the opt-in
+  if (v.lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
+      return fail(LORA_HIP_EHIP);
+  }
+  (void)rc;
+  *out = h;
+  return LORA_HIP_OK;
+}
+
+void lora_hip_demod_destroy(lora_hip_demod_t *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
+  (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_idx); (void)hipFree(h->d_val);
+  delete h;
+}
+
+int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream) {
+  if (!h) return LORA_HIP_EINVAL;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return LORA_HIP_OK;
+}
+
+unsigned lora_hip_demod_sf(const lora_hip_demod_t *h) { return h ? h->sf : 0; }
+unsigned lora_hip_demod_fft_factor(const lora_hip_demod_t *h) { return h ? h->fft_factor : 0; }
+const char *lora_hip_demod_kernel_name(const lora_hip_demod_t *h) { return h ? h->kernel_name : ""; }
+
+static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, KParams &p,
+                     const lora_win_desc *desc, size_t n_win, uint16_t *max_idx, float *max_val, unsigned flags) {
+  if (!h || (!iq && n_samples) || (n_win && (!max_idx || !max_val))) return LORA_HIP_EINVAL;
+  if (n_win > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
+  const bool iq_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
+  const bool desc_dev = flags & LORA_HIP_DESC_ON_DEVICE;
+  if ((flags & LORA_HIP_ASYNC) && (!iq_dev || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
+  if (n_win == 0) return LORA_HIP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  // inputs
+  if (iq_dev) p.iq = reinterpret_cast<const float2 *>(iq);
+  else {
+    if ((rc = grow(h, &h->d_iq, &h->cap_iq, n_samples)) != LORA_HIP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    p.iq = h->d_iq;
+  }
+  p.n_samples = n_samples;
+  if (desc) {
+    if (desc_dev) p.desc = desc;
+    else {
+      // host descriptors: validate here so that a bad window is an error, not a sentinel
+      for (size_t i = 0; i < n_win; i++) {
+        if (desc[i].kind > LORA_WIN_SFD || desc[i].chirp_off >= h->n) return LORA_HIP_EINVAL;
+        if (desc[i].pos > n_samples || n_samples - desc[i].pos < h->n) return LORA_HIP_EINVAL;
+      }
+      size_t bytes = n_win * sizeof(lora_win_desc);
+      if ((rc = grow(h, reinterpret_cast<unsigned char **>(&h->d_desc), &h->cap_desc, bytes)) != LORA_HIP_OK) return rc;
+      HIP_TRY(h, hipMemcpyAsync(h->d_desc, desc, bytes, hipMemcpyHostToDevice, h->stream));
+      p.desc = h->d_desc;
+    }
+  } else p.desc = nullptr;
+  // outputs
+  if (out_dev) { p.out_idx = max_idx; p.out_val = max_val; }
+  else {
+    if (n_win > h->cap_out) {
+      size_t c1 = h->cap_out, c2 = h->cap_out;
+      if ((rc = grow(h, &h->d_idx, &c1, n_win)) != LORA_HIP_OK) return rc;
+      if ((rc = grow(h, &h->d_val, &c2, n_win)) != LORA_HIP_OK) return rc;
+      h->cap_out = c1 < c2 ? c1 : c2;
+    }
+    p.out_idx = h->d_idx; p.out_val = h->d_val;
+  }
+  p.up = h->d_up; p.down = h->d_down; p.win = h->d_win; p.twc = h->d_tw;
+  for (int ps = 0; ps < 3; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
+  p.n_win = (unsigned)n_win;
+  if ((rc = launch(h, p)) != LORA_HIP_OK) return rc;
+  if (!out_dev) {
+    HIP_TRY(h, hipMemcpyAsync(max_idx, h->d_idx, n_win * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(max_val, h->d_val, n_win * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return LORA_HIP_OK;
+}
+
+int lora_hip_demod_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, const lora_win_desc *desc,
+                         size_t n_win, uint16_t *max_idx, float *max_val, unsigned flags) {
+  if (n_win && !desc) return LORA_HIP_EINVAL;
+  KParams p;
+  memset(&p, 0, sizeof p);
+  return run_batch(h, iq, n_samples, p, desc, n_win, max_idx, max_val, flags);
+}
+
+int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, uint64_t pos0,
+                                 uint64_t stride, size_t count, unsigned chirp_off, unsigned chirp_off_step,
+                                 unsigned kind, uint16_t *max_idx, float *max_val, unsigned flags) {
+  if (!h) return LORA_HIP_EINVAL;
+  if (kind > LORA_WIN_SFD || chirp_off >= h->n || chirp_off_step >= h->n) return LORA_HIP_EINVAL;
+  if (count) {
+    // last window must end inside the capture (overflow-safe)
+    if (pos0 > n_samples || n_samples - pos0 < h->n) return LORA_HIP_EINVAL;
+    const uint64_t room = n_samples - pos0 - h->n;
+    if (count > 1 && (stride == 0 ? false : (count - 1) > room / stride)) return LORA_HIP_EINVAL;
+  }
+  KParams p;
+  memset(&p, 0, sizeof p);
+  p.pos0 = pos0; p.stride = stride; p.off0 = chirp_off; p.off_step = chirp_off_step; p.kind = kind;
+  return run_batch(h, iq, n_samples, p, nullptr, count, max_idx, max_val, flags);
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+/*
+ * lora_hip_demod.h -- C ABI of the MI355X (gfx950) LoRa chirp demodulator hot path.
+ *
+ * Drop-in boundary for the per-symbol numeric loop of gr-lora's demod block
+ * (reference: lib/demod_impl.cc:149-450, demod_impl::general_work).  Everything here is plain C:
+ * pointers and sizes, no C++/torch/HIP types in the signatures.  All functions return 0 on
+ * success or a negative LORA_HIP_E* code; nothing throws across the boundary.
+ *
+ * Threading: a handle is used by one thread at a time; distinct handles are independent and may
+ * live on different GPUs (one handle per device for multi-GPU).  No global mutable state.
+ */
+#ifndef LORA_HIP_DEMOD_H
+#define LORA_HIP_DEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define LORA_HIP_API __attribute__((visibility("default")))   /* mirrors LORA_API, include/lora/api.h */
+#else
+#define LORA_HIP_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* interleaved complex64 == gr_complex == std::complex<float> == float2 */
+typedef struct { float re, im; } lora_c32;
+
+typedef struct lora_hip_demod lora_hip_demod_t;
+
+enum {
+  LORA_HIP_OK = 0,
+  LORA_HIP_EINVAL = -1,        /* bad argument (NULL, sf outside 6..12, window past the buffer) */
+  LORA_HIP_EUNSUPPORTED = -2,  /* fft_factor not in {1,2,4} */
+  LORA_HIP_ENOMEM = -3,        /* host or device allocation failed */
+  LORA_HIP_EHIP = -4,          /* a HIP runtime call failed; see lora_hip_last_hip_error() */
+  LORA_HIP_ENODEVICE = -5      /* no usable gfx950 device / device index out of range */
+};
+
+/* window kinds: which dechirp the window gets */
+enum {
+  LORA_WIN_UP = 0,   /* in * downchirp[chirp_off + n] * kaiser[n]   demod_impl.cc:177-192 */
+  LORA_WIN_SFD = 1   /* in * upchirp[chirp_off + n], no window       demod_impl.cc:300-310 */
+};
+
+/* flags for the batch calls */
+enum {
+  LORA_HIP_IQ_ON_DEVICE = 1,    /* iq is a device pointer (HBM resident), else host memory */
+  LORA_HIP_OUT_ON_DEVICE = 2,   /* max_idx / max_val are device pointers, else host memory */
+  LORA_HIP_DESC_ON_DEVICE = 4,  /* desc is a device pointer */
+  LORA_HIP_ASYNC = 8            /* do not synchronise the handle's stream before returning
+                                   (only valid when every buffer named above is on the device) */
+};
+
+/* one symbol window: N = 2^sf samples starting at iq[pos] */
+typedef struct {
+  uint64_t pos;        /* first sample of the window                                   */
+  uint16_t chirp_off;  /* offset into the 2N-entry chirp table (d_offset), 0 <= off < N  */
+  uint8_t  kind;       /* LORA_WIN_UP / LORA_WIN_SFD                                    */
+  uint8_t  reserved[5];
+} lora_win_desc;       /* 16 bytes */
+
+LORA_HIP_API const char *lora_hip_strerror(int code);
+/* text of the last HIP error seen by this handle (valid until the next call on it) */
+LORA_HIP_API const char *lora_hip_last_hip_error(const lora_hip_demod_t *h);
+
+/*
+ * Host-side table builders.  They restate, in double/float exactly as the reference does:
+ *   chirp tables  -- lib/demod_impl.cc:92-101 (float phase, double accumulator, polar in double)
+ *   Kaiser window -- fft::window::build(WIN_KAISER, N, beta), call site lib/demod_impl.cc:85
+ * up_2n / down_2n hold 2*2^sf entries, window_n holds 2^sf.
+ */
+LORA_HIP_API int lora_hip_make_chirp_tables(unsigned sf, lora_c32 *up_2n, lora_c32 *down_2n);
+LORA_HIP_API int lora_hip_make_kaiser(unsigned ntaps, double beta, float *window_n);
+
+/*
+ * Replaces the constructor state of demod_impl (lib/demod_impl.cc:54-104): FFT plan (:81),
+ * window (:85) and chirp tables (:92-101) are copied to HBM of `device`; the caller keeps
+ * ownership of the three host arrays.  Passing NULL for all three makes the library build them
+ * with the functions above from (sf, beta).  One HIP stream is created per handle.
+ */
+LORA_HIP_API int lora_hip_demod_create(lora_hip_demod_t **h, int device, unsigned sf,
+                                       unsigned fft_factor, float beta, const float *window_n,
+                                       const lora_c32 *upchirp_2n, const lora_c32 *downchirp_2n);
+LORA_HIP_API void lora_hip_demod_destroy(lora_hip_demod_t *h);
+
+/* Run the batch calls on a caller-owned hipStream_t (passed as void*); NULL restores the
+ * handle's own stream. */
+LORA_HIP_API int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream);
+
+/*
+ * The hot path.  For each window i < n_win this computes what one general_work call computes
+ * between lib/demod_impl.cc:177 and :206 (kind UP) or one iteration of the SFD loop
+ * :297-322 (kind SFD):
+ *     x[n]  = iq[pos+n] * chirp[chirp_off+n]  (* kaiser[n] for UP), n < N
+ *     X     = forward DFT of x zero-padded to M = N*fft_factor points
+ *     max_idx[i] = lowest k with maximal |X[k]|^2   (demod_impl::argmax, :114-140)
+ *     max_val[i] = that |X[k]|^2                    (d_power when update_squelch)
+ * A window with pos+N > n_samples is an error (LORA_HIP_EINVAL) when the descriptors are on the
+ * host; descriptors on the device are guarded in the kernel and yield max_idx 0xFFFF, val -1.
+ */
+LORA_HIP_API int lora_hip_demod_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples,
+                                      const lora_win_desc *desc, size_t n_win,
+                                      uint16_t *max_idx, float *max_val, unsigned flags);
+
+/* Same for `count` windows at pos0 + i*stride with one chirp_off and kind: the stride-N sweep of
+ * S_DETECT_PREAMBLE / S_READ_* (consume_each(N), :443) and the stride-N/16 sweep of S_SFD_SYNC
+ * when chirp_off_step != 0: window i uses chirp_off = (chirp_off + i*chirp_off_step) mod N
+ * (d_offset = (ol*N/16) % N, :297). */
+LORA_HIP_API int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c32 *iq,
+                                              size_t n_samples, uint64_t pos0, uint64_t stride,
+                                              size_t count, unsigned chirp_off,
+                                              unsigned chirp_off_step, unsigned kind,
+                                              uint16_t *max_idx, float *max_val, unsigned flags);
+
+/* geometry of the handle */
+LORA_HIP_API unsigned lora_hip_demod_sf(const lora_hip_demod_t *h);
+LORA_HIP_API unsigned lora_hip_demod_fft_factor(const lora_hip_demod_t *h);
+/* name of the kernel the handle dispatches to (for profiles) */
+LORA_HIP_API const char *lora_hip_demod_kernel_name(const lora_hip_demod_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORA_HIP_DEMOD_H */
