@@ -4,3 +4,4 @@ mirrors the reference's repository name), so import it through the `gr_lora_amd`
 repository root or with importlib.import_module("gr-lora_amd")."""
 from . import capi  # noqa: F401
 from .capi import HipDemod, LoraHipError, make_chirp_tables, make_kaiser, make_desc  # noqa: F401
+from .demod import demod  # noqa: F401,E402

@@ -1,0 +1,314 @@
+// demod_core.cpp -- host side of the demod block (include/lora_demod_core.h).
+//
+// The reference evaluates one FFT per general_work call and decides what to look at next from
+// the result (lib/demod_impl.cc:214-437).  Here the same integer state machine runs on the host
+// over (argmax, max) pairs that the GPU produced in speculative batches:
+//   * up-path windows lie on a stride-N lattice until the next SFD lock, so a miss at (pos, off)
+//     launches one strided batch from pos to as far as samples are available (geometric growth);
+//   * entering S_SFD_SYNC launches one stride-N/16 batch that covers the at most 10 calls x 16
+//     overlapped windows the reference can evaluate before it bails out (:283-292).
+// Every decision (tolerances, counters, integer divisions, squelch compare) is the reference's.
+// Product code: never calls anything under oracle/.
+#include "lora_demod_core.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// include/lora/demod.h:28-33
+#define DEMOD_HISTORY_DEPTH 3
+#define REQUIRED_PREAMBLE_CHIRPS 4
+#define REQUIRED_SFD_CHIRPS 2
+#define LORA_SFD_TOLERANCE 1
+#define LORA_PREAMBLE_TOLERANCE 1
+#define DEMOD_SYNC_RECOVERY_COUNT (8 - REQUIRED_PREAMBLE_CHIRPS) + (2 - REQUIRED_SFD_CHIRPS) + 4
+// lib/demod_impl.cc:35-36
+#define OVERLAP_DEFAULT 1
+#define OVERLAP_FACTOR 16
+
+namespace {
+
+// results of one strided GPU batch: window k starts at start + k*stride
+struct Run {
+  uint64_t start = 0, stride = 1;
+  unsigned off0 = 0, off_step = 0, kind = 0;
+  std::vector<uint16_t> idx;
+  std::vector<float> val;
+  bool find(uint64_t pos, unsigned off, unsigned n, size_t *k) const {
+    if (idx.empty() || pos < start) return false;
+    const uint64_t d = pos - start;
+    if (d % stride) return false;
+    const uint64_t q = d / stride;
+    if (q >= idx.size()) return false;
+    if (((off0 + q * off_step) & (n - 1)) != off) return false;
+    *k = (size_t)q;
+    return true;
+  }
+};
+
+}  // namespace
+
+struct lora_demod_core {
+  // configuration (demod_impl.h:44-49)
+  unsigned d_sf = 0; bool d_ldr = false; float d_beta = 0; unsigned d_fft_size_factor = 0;
+  unsigned d_num_symbols = 0, d_fft_size = 0;
+  lora_hip_demod_t *hip = nullptr;
+  // reference state (demod_impl.h:43-70)
+  int d_state = LORA_S_RESET;
+  unsigned d_overlaps = OVERLAP_DEFAULT, d_offset = 0;
+  float d_power = .000000001f, d_threshold = 0.005f;      // :87-88
+  bool d_squelched = false;
+  unsigned d_preamble_idx = 0, d_sfd_idx = 0;
+  std::vector<unsigned short> d_argmax_history, d_sfd_history;
+  unsigned d_sync_recovery_counter = 0;
+  std::vector<unsigned short> d_symbols;
+  // stream framing: buf holds stream samples [base, base + buf.size()); pos = read index
+  std::vector<lora_c32> buf;
+  uint64_t base = 0, pos = 0;
+  // GPU result caches
+  Run up_run, sfd_run;
+  size_t next_spec = 64;
+  bool staged = false;
+  // instrumentation
+  lora_core_trace *trace = nullptr; size_t max_trace = 0;
+  uint64_t n_calls = 0, n_windows = 0, n_launches = 0;
+  std::string err;
+};
+
+namespace {
+
+constexpr size_t kMinSpec = 64, kMaxSpec = 1u << 16;
+
+int fail(lora_demod_core *c, int rc, const char *what) {
+  c->err = std::string(what) + ": " + lora_hip_strerror(rc);
+  if (rc == LORA_HIP_EHIP) c->err += std::string(" [") + lora_hip_last_hip_error(c->hip) + "]";
+  return rc;
+}
+
+int ensure_staged(lora_demod_core *c) {
+  if (c->staged) return LORA_HIP_OK;
+  int rc = lora_hip_demod_stage_iq(c->hip, c->buf.data(), c->buf.size());
+  if (rc) return fail(c, rc, "stage_iq");
+  c->staged = true;
+  return LORA_HIP_OK;
+}
+
+int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size_t count, unsigned off0,
+               unsigned off_step, unsigned kind) {
+  int rc = ensure_staged(c);
+  if (rc) return rc;
+  r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
+  r.idx.assign(count, 0); r.val.assign(count, 0.f);
+  rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->buf.size(), start - c->base, stride, count, off0, off_step,
+                                    kind, r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+  if (rc) { r.idx.clear(); r.val.clear(); return fail(c, rc, "batch_strided"); }
+  c->n_windows += count; c->n_launches++;
+  return LORA_HIP_OK;
+}
+
+// (argmax, max) of the up path at (pos, off): lib/demod_impl.cc:177-206
+int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, float *val) {
+  const unsigned n = c->d_num_symbols;
+  size_t k;
+  if (!c->up_run.find(pos, off, n, &k)) {
+    // windows available from pos on this lattice; speculate geometrically
+    const uint64_t end = c->base + c->buf.size();
+    const size_t avail = (size_t)((end - pos - n) / n + 1);
+    const bool continues = !c->up_run.idx.empty() && c->up_run.stride == n && c->up_run.off0 == off &&
+                           pos == c->up_run.start + (uint64_t)c->up_run.idx.size() * n;
+    c->next_spec = continues ? (c->next_spec * 2 > kMaxSpec ? kMaxSpec : c->next_spec * 2) : kMinSpec;
+    const size_t count = avail < c->next_spec ? avail : c->next_spec;
+    int rc = launch_run(c, c->up_run, pos, n, count, off, 0, LORA_WIN_UP);
+    if (rc) return rc;
+    k = 0;
+  }
+  *idx = c->up_run.idx[k]; *val = c->up_run.val[k];
+  return LORA_HIP_OK;
+}
+
+// argmax of one overlapped SFD window: lib/demod_impl.cc:297-322
+int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx) {
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  size_t k;
+  if (!c->sfd_run.find(call_pos + off, off, n, &k)) {
+    // cover the rest of this call and the following calls of the sync attempt
+    const uint64_t end = c->base + c->buf.size();
+    const uint64_t first = call_pos + off;
+    size_t avail = (size_t)((end - first - n) / step + 1);
+    size_t want = (size_t)OVERLAP_FACTOR * 10 + OVERLAP_FACTOR;
+    int rc = launch_run(c, c->sfd_run, first, step, avail < want ? avail : want, off, step, LORA_WIN_SFD);
+    if (rc) return rc;
+    k = 0;
+  }
+  *idx = c->sfd_run.idx[k];
+  return LORA_HIP_OK;
+}
+
+// One general_work call at c->pos (lib/demod_impl.cc:149-450).  *consumed = num_consumed.
+int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consumed) {
+  const unsigned N = c->d_num_symbols, F = c->d_fft_size_factor;
+  unsigned num_consumed = N;
+  unsigned short max_index = 0;
+  bool preamble_found = false, sfd_found = false;
+  const int st_in = c->d_state;
+  unsigned n_sfd = 0;
+
+  // :177-206 up path; chirp offset is d_offset only while reading header/payload
+  const unsigned off = (c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) ? c->d_offset : 0;
+  float max_val = 0.f;
+  int rc = get_up(c, c->pos, off, &max_index, &max_val);
+  if (rc) return rc;
+  const unsigned short up_idx = max_index;
+  // argmax(..., update_squelch = true), :133-137
+  c->d_power = max_val;
+  c->d_squelched = (c->d_power > c->d_threshold) ? false : true;
+  // :207-212
+  c->d_argmax_history.insert(c->d_argmax_history.begin(), max_index);
+  if (c->d_argmax_history.size() > REQUIRED_PREAMBLE_CHIRPS) c->d_argmax_history.pop_back();
+
+  switch (c->d_state) {
+    case LORA_S_RESET:                                              // :215-229
+      c->d_overlaps = OVERLAP_DEFAULT;
+      c->d_offset = 0;
+      c->d_symbols.clear();
+      c->d_argmax_history.clear();
+      c->d_sfd_history.clear();
+      c->d_sync_recovery_counter = 0;
+      c->d_state = LORA_S_PREFILL;
+      break;
+
+    case LORA_S_PREFILL:                                            // :233-242
+      if (c->d_argmax_history.size() >= REQUIRED_PREAMBLE_CHIRPS) c->d_state = LORA_S_DETECT_PREAMBLE;
+      break;
+
+    case LORA_S_DETECT_PREAMBLE:                                    // :247-273
+      c->d_preamble_idx = c->d_argmax_history[0];
+      preamble_found = true;
+      for (int i = 1; i < REQUIRED_PREAMBLE_CHIRPS; i++)
+        if (abs(int(c->d_preamble_idx) - int(c->d_argmax_history[i])) > LORA_PREAMBLE_TOLERANCE) preamble_found = false;
+      if (preamble_found && !c->d_squelched) c->d_state = LORA_S_SFD_SYNC;
+      break;
+
+    case LORA_S_SFD_SYNC:                                           // :279-359
+      c->d_overlaps = OVERLAP_FACTOR;
+      if (c->d_sync_recovery_counter++ > DEMOD_SYNC_RECOVERY_COUNT) {
+        c->d_state = LORA_S_RESET;
+        c->d_overlaps = OVERLAP_DEFAULT;
+      }
+      for (int ol = 0; ol < (int)c->d_overlaps; ol++) {
+        c->d_offset = ((ol * N) / c->d_overlaps) % N;
+        if ((rc = get_sfd(c, c->pos, c->d_offset, &max_index))) return rc;
+        n_sfd++;
+        c->d_sfd_history.insert(c->d_sfd_history.begin(), max_index);
+        if (c->d_sfd_history.size() > REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR) {
+          c->d_sfd_history.pop_back();
+          sfd_found = true;
+          c->d_sfd_idx = c->d_sfd_history[0];
+          for (int i = 1; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++)
+            if (abs(int(c->d_sfd_idx) - int(c->d_sfd_history[i])) > int(F) * LORA_SFD_TOLERANCE) sfd_found = false;
+          if (sfd_found) {
+            num_consumed = (ol * N) / c->d_overlaps + 5 * N / 4;   // skip last quarter chirp
+            c->d_offset = (c->d_offset + (N / 4)) % N;
+            c->d_state = LORA_S_READ_HEADER;
+            c->d_overlaps = OVERLAP_DEFAULT;
+            break;
+          }
+        }
+      }
+      break;
+
+    case LORA_S_READ_HEADER:                                        // :363-387
+      if (c->d_squelched) c->d_state = LORA_S_OUT;
+      else if (c->d_symbols.size() == 7) c->d_state = LORA_S_READ_PAYLOAD;
+      c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
+      break;
+
+    case LORA_S_READ_PAYLOAD:                                       // :391-413
+      if (c->d_squelched) c->d_state = LORA_S_OUT;
+      if (c->d_ldr)
+        c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
+      else
+        c->d_symbols.push_back((unsigned short)((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N));
+      break;
+
+    case LORA_S_OUT:                                                // :418-431
+      if (cb) cb(user, c->d_symbols.data(), c->d_symbols.size());
+      c->d_state = LORA_S_RESET;
+      break;
+
+    default:
+      break;
+  }
+
+  if (c->trace && c->n_calls < c->max_trace) {
+    lora_core_trace &t = c->trace[c->n_calls];
+    t.pos = c->pos; t.state = (uint16_t)st_in; t.chirp_off = (uint16_t)off; t.idx = up_idx;
+    t.consumed = (uint16_t)num_consumed; t.val = max_val; t.n_sfd = n_sfd;
+  }
+  c->n_calls++;
+  *consumed = num_consumed & 0xFFFFu;     // num_consumed is an unsigned short in the reference (:157)
+  return LORA_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int ldr, float beta, unsigned fft_factor) {
+  if (!out) return LORA_HIP_EINVAL;
+  *out = nullptr;
+  lora_demod_core *c = new (std::nothrow) lora_demod_core();
+  if (!c) return LORA_HIP_ENOMEM;
+  int rc = lora_hip_demod_create(&c->hip, device, sf, fft_factor, beta, nullptr, nullptr, nullptr);
+  if (rc) { delete c; return rc; }
+  c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor;
+  c->d_num_symbols = 1u << sf;                                      // :79
+  c->d_fft_size = c->d_fft_size_factor * c->d_num_symbols;          // :80
+  // set_history(DEMOD_HISTORY_DEPTH * N), :103: the scheduler presents history()-1 zeros first
+  c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
+  *out = c;
+  return LORA_HIP_OK;
+}
+
+void lora_demod_core_destroy(lora_demod_core_t *c) {
+  if (!c) return;
+  lora_hip_demod_destroy(c->hip);
+  delete c;
+}
+
+int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, lora_pdu_cb cb, void *user) {
+  if (!c || (!in && n_in)) return LORA_HIP_EINVAL;
+  if (n_in) { c->buf.insert(c->buf.end(), in, in + n_in); c->staged = false; }
+  const uint64_t need = (uint64_t)c->d_num_symbols + (uint64_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1;
+  while (c->base + c->buf.size() >= c->pos + need) {
+    unsigned consumed = 0;
+    int rc = general_work(c, cb, user, &consumed);
+    if (rc) return rc;
+    c->pos += consumed;                                             // consume_each, :443
+  }
+  // drop what can never be read again; cached runs keep absolute positions
+  if (c->pos > c->base) {
+    const size_t drop = (size_t)(c->pos - c->base);
+    c->buf.erase(c->buf.begin(), c->buf.begin() + (drop < c->buf.size() ? drop : c->buf.size()));
+    c->base += drop;
+    c->staged = false;
+  }
+  return LORA_HIP_OK;
+}
+
+int lora_demod_core_set_trace(lora_demod_core_t *c, lora_core_trace *rows, size_t max_rows) {
+  if (!c) return LORA_HIP_EINVAL;
+  c->trace = rows; c->max_trace = rows ? max_rows : 0;
+  return LORA_HIP_OK;
+}
+
+uint64_t lora_demod_core_calls(const lora_demod_core_t *c) { return c ? c->n_calls : 0; }
+uint64_t lora_demod_core_windows(const lora_demod_core_t *c) { return c ? c->n_windows : 0; }
+uint64_t lora_demod_core_launches(const lora_demod_core_t *c) { return c ? c->n_launches : 0; }
+int lora_demod_core_state(const lora_demod_core_t *c) { return c ? c->d_state : -1; }
+const char *lora_demod_core_last_error(const lora_demod_core_t *c) { return c ? c->err.c_str() : ""; }
+
+}  // extern "C"

@@ -20,7 +20,7 @@ struct lora_hip_demod {
   size_t tw_off[3] = {0, 0, 0};
   float *d_win = nullptr;
   // staging for host-resident arguments (grown on demand, reused)
-  float2 *d_iq = nullptr; size_t cap_iq = 0;
+  float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
   void *d_desc = nullptr; size_t cap_desc = 0;
   unsigned short *d_idx = nullptr; float *d_val = nullptr; size_t cap_out = 0;
   char hip_err[256] = {0};
@@ -234,23 +234,39 @@ int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream) {
   return LORA_HIP_OK;
 }
 
+int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples) {
+  if (!h || (!iq && n_samples)) return LORA_HIP_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  h->staged_n = 0;
+  int rc = grow(h, &h->d_iq, &h->cap_iq, n_samples ? n_samples : 1);
+  if (rc != LORA_HIP_OK) return rc;
+  if (n_samples) HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));     // the host buffer may be reused by the caller
+  h->staged_n = n_samples;
+  return LORA_HIP_OK;
+}
+
 unsigned lora_hip_demod_sf(const lora_hip_demod_t *h) { return h ? h->sf : 0; }
 unsigned lora_hip_demod_fft_factor(const lora_hip_demod_t *h) { return h ? h->fft_factor : 0; }
 const char *lora_hip_demod_kernel_name(const lora_hip_demod_t *h) { return h ? h->kernel_name : ""; }
 
 static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, KParams &p,
                      const lora_win_desc *desc, size_t n_win, uint16_t *max_idx, float *max_val, unsigned flags) {
-  if (!h || (!iq && n_samples) || (n_win && (!max_idx || !max_val))) return LORA_HIP_EINVAL;
+  const bool iq_staged = flags & LORA_HIP_IQ_STAGED;
+  if (!h || (!iq && n_samples && !iq_staged) || (n_win && (!max_idx || !max_val))) return LORA_HIP_EINVAL;
+  if (iq_staged && (n_samples > h->staged_n || (flags & LORA_HIP_IQ_ON_DEVICE))) return LORA_HIP_EINVAL;
   if (n_win > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
   const bool iq_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
   const bool desc_dev = flags & LORA_HIP_DESC_ON_DEVICE;
-  if ((flags & LORA_HIP_ASYNC) && (!iq_dev || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
+  if ((flags & LORA_HIP_ASYNC) && ((!iq_dev && !iq_staged) || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
   if (n_win == 0) return LORA_HIP_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   int rc;
   // inputs
   if (iq_dev) p.iq = reinterpret_cast<const float2 *>(iq);
+  else if (iq_staged) p.iq = h->d_iq;
   else {
+    h->staged_n = 0;
     if ((rc = grow(h, &h->d_iq, &h->cap_iq, n_samples)) != LORA_HIP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     p.iq = h->d_iq;

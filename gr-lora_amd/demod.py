@@ -1,0 +1,92 @@
+"""Python mirror of the reference's block interface for the demod path.
+
+    lora.demod(spreading_factor, low_data_rate, beta, fft_factor)        grc/lora_demod.xml:7
+    gr::lora::demod::make(unsigned short, bool, float, unsigned short)   include/lora/demod.h:66-69
+
+Same argument order, meaning and defaults (SF 8, False, 25.0, 2: grc/lora_demod.xml:12-30).  The
+block has one complex64 input stream and one message port "out" that carries
+cons(make_dict(), u16vector) PDUs (lib/demod_impl.cc:58-60,74-75,420-422); here a PDU is the pair
+({}, numpy uint16 array).  All numeric work runs on the GPU through the C ABI
+(include/lora_demod_core.h -> include/lora_hip_demod.h); there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class demod:
+    """gr::lora::demod without GNU Radio: feed samples with work(), collect PDUs."""
+
+    name = "demod"                       # gr::block("demod", ...), lib/demod_impl.cc:58
+    out_port = "out"                     # pmt::mp("out"), lib/demod_impl.cc:74
+
+    def __init__(self, spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0):
+        # asserts of lib/demod_impl.cc:70-72 (compiled out in the reference's Release build)
+        if not (5 < spreading_factor < 13):
+            raise ValueError("spreading_factor must be in 6..12")
+        if fft_factor <= 0:
+            raise ValueError("fft_factor must be > 0")
+        self.spreading_factor, self.low_data_rate = int(spreading_factor), bool(low_data_rate)
+        self.beta, self.fft_factor = float(beta), int(fft_factor)
+        self._h = C.c_void_p()
+        rc = capi.lib().lora_demod_core_create(C.byref(self._h), device, self.spreading_factor,
+                                               int(self.low_data_rate), self.beta, self.fft_factor)
+        if rc:
+            self._h = None
+            raise capi.LoraHipError(rc)
+        self._handlers = []
+        self._pending = []
+        self._trace = None
+        self._cb = capi.PDU_CB(self._on_pdu)     # keep the callback object alive
+
+    @staticmethod
+    def make(spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0):
+        return demod(spreading_factor, low_data_rate, beta, fft_factor, device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().lora_demod_core_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def history(self):
+        return 3 * (1 << self.spreading_factor)       # set_history(DEMOD_HISTORY_DEPTH*N), :103
+
+    def forecast(self, noutput_items):
+        return noutput_items * (1 << self.spreading_factor)    # :142-147
+
+    def message_subscribe(self, handler):
+        """handler(pdu) is called for every PDU published on port "out"."""
+        self._handlers.append(handler)
+
+    def _on_pdu(self, _user, syms, n):
+        pdu = ({}, np.ctypeslib.as_array(syms, (n,)).copy() if n else np.zeros(0, np.uint16))
+        self._pending.append(pdu)
+        for h in self._handlers:
+            h(pdu)
+
+    def enable_trace(self, max_rows):
+        self._trace = np.zeros(max_rows, capi.CORE_TRACE_DTYPE)
+        capi.lib().lora_demod_core_set_trace(self._h, self._trace.ctypes.data, max_rows)
+
+    def trace(self):
+        n = min(int(capi.lib().lora_demod_core_calls(self._h)), len(self._trace))
+        return self._trace[:n]
+
+    def work(self, samples):
+        """Feed complex64 samples; returns the PDUs completed by this call as u16 arrays."""
+        x = np.ascontiguousarray(samples, np.complex64)
+        self._pending = []
+        rc = capi.lib().lora_demod_core_work(self._h, x.ctypes.data, len(x), self._cb, None)
+        if rc:
+            raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
+        return [p[1] for p in self._pending]
+
+    @property
+    def stats(self):
+        L = capi.lib()
+        return dict(calls=int(L.lora_demod_core_calls(self._h)), windows=int(L.lora_demod_core_windows(self._h)),
+                    launches=int(L.lora_demod_core_launches(self._h)), state=int(L.lora_demod_core_state(self._h)))

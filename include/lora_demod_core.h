@@ -1,0 +1,73 @@
+/*
+ * lora_demod_core.h -- GNU-Radio-free host side of the demod block, above lora_hip_demod.h.
+ *
+ * Replaces the body of gr::lora::demod_impl (reference: lib/demod_impl.cc:54-104 constructor,
+ * :149-450 general_work) minus the GNU Radio plumbing: it owns the stream framing
+ * (set_history(3N), :103), the integer sync/framing state machine (:214-437), the squelch
+ * (:133-137) and PDU assembly (:420-422), and obtains every (argmax, max) pair from the GPU
+ * through lora_hip_demod_batch_strided in speculative batches instead of one FFT per call.
+ * The sequence of PDUs equals what the reference emits for the same sample stream.
+ *
+ * The GNU Radio adapter (gr-lora_amd/gr_adapter/) subclasses gr::lora::demod, feeds
+ * general_work's new input items to lora_demod_core_work and publishes each PDU as
+ * pmt::cons(pmt::make_dict(), pmt::init_u16vector(n, symbols)) on message port "out".
+ */
+#ifndef LORA_DEMOD_CORE_H
+#define LORA_DEMOD_CORE_H
+
+#include "lora_hip_demod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lora_demod_core lora_demod_core_t;
+
+/* include/lora/demod.h:38-46 */
+enum lora_demod_state {
+  LORA_S_RESET = 0, LORA_S_PREFILL, LORA_S_DETECT_PREAMBLE, LORA_S_SFD_SYNC,
+  LORA_S_READ_HEADER, LORA_S_READ_PAYLOAD, LORA_S_OUT
+};
+
+/* One PDU: the u16vector of lib/demod_impl.cc:420 (first 8 symbols /4, then full SF bits or /4
+ * under low_data_rate, trailing squelch symbol included; not gray-mapped). */
+typedef void (*lora_pdu_cb)(void *user, const uint16_t *symbols, size_t n_symbols);
+
+/* One row per emulated general_work call (for tests and debugging). */
+typedef struct {
+  uint64_t pos;        /* read index into the framed stream (3N-1 zeros ++ samples fed so far) */
+  uint16_t state;      /* d_state on entry */
+  uint16_t chirp_off;  /* downchirp offset of the up path (d_offset in READ_*, else 0) */
+  uint16_t idx;        /* argmax of the up path */
+  uint16_t consumed;   /* num_consumed (:443) */
+  float    val;        /* d_power */
+  uint32_t n_sfd;      /* SFD windows evaluated in this call */
+} lora_core_trace;
+
+/* gr::lora::demod::make(spreading_factor, low_data_rate, beta, fft_factor)
+ * (include/lora/demod.h:66-69, lib/demod_impl.cc:41-49) plus the GPU index. */
+LORA_HIP_API int lora_demod_core_create(lora_demod_core_t **c, int device, unsigned spreading_factor,
+                                        int low_data_rate, float beta, unsigned fft_factor);
+LORA_HIP_API void lora_demod_core_destroy(lora_demod_core_t *c);
+
+/* Feed n_in new samples (host memory).  Runs every general_work call that GNU Radio's scheduler
+ * could run with the samples fed so far (a call needs N + history-1 = 4N-1 samples from its read
+ * index: forecast :142-147 with noutput_items = 1) and reports PDUs through cb in stream order.
+ * Samples that are not yet consumable stay buffered inside the core. */
+LORA_HIP_API int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in,
+                                      lora_pdu_cb cb, void *user);
+
+/* Optional per-call trace: rows are appended to `rows` (caller-owned) up to max_rows; the number
+ * of calls so far (may exceed max_rows) is returned by lora_demod_core_calls(). */
+LORA_HIP_API int lora_demod_core_set_trace(lora_demod_core_t *c, lora_core_trace *rows, size_t max_rows);
+LORA_HIP_API uint64_t lora_demod_core_calls(const lora_demod_core_t *c);
+/* GPU work issued so far: symbol windows evaluated and kernel launches */
+LORA_HIP_API uint64_t lora_demod_core_windows(const lora_demod_core_t *c);
+LORA_HIP_API uint64_t lora_demod_core_launches(const lora_demod_core_t *c);
+LORA_HIP_API int lora_demod_core_state(const lora_demod_core_t *c);
+LORA_HIP_API const char *lora_demod_core_last_error(const lora_demod_core_t *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORA_DEMOD_CORE_H */

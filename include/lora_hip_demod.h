@@ -50,8 +50,10 @@ enum {
   LORA_HIP_IQ_ON_DEVICE = 1,    /* iq is a device pointer (HBM resident), else host memory */
   LORA_HIP_OUT_ON_DEVICE = 2,   /* max_idx / max_val are device pointers, else host memory */
   LORA_HIP_DESC_ON_DEVICE = 4,  /* desc is a device pointer */
-  LORA_HIP_ASYNC = 8            /* do not synchronise the handle's stream before returning
+  LORA_HIP_ASYNC = 8,           /* do not synchronise the handle's stream before returning
                                    (only valid when every buffer named above is on the device) */
+  LORA_HIP_IQ_STAGED = 16       /* iq is ignored: use the samples last given to
+                                   lora_hip_demod_stage_iq (n_samples must not exceed them) */
 };
 
 /* one symbol window: N = 2^sf samples starting at iq[pos] */
@@ -114,6 +116,11 @@ LORA_HIP_API int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c3
                                               size_t count, unsigned chirp_off,
                                               unsigned chirp_off_step, unsigned kind,
                                               uint16_t *max_idx, float *max_val, unsigned flags);
+
+/* Copy n_samples host samples into the handle's own HBM staging buffer once, so that several
+ * batch calls (flag LORA_HIP_IQ_STAGED) can sweep them without another host-to-device copy.
+ * This is what replaces the scheduler-owned input buffer of general_work (:155). */
+LORA_HIP_API int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples);
 
 /* geometry of the handle */
 LORA_HIP_API unsigned lora_hip_demod_sf(const lora_hip_demod_t *h);
