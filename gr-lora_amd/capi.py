@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblora_hip_demod.so")
+LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip_demod.so")
 
 OK, EINVAL, EUNSUPPORTED, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4, -5
 WIN_UP, WIN_SFD = 0, 1

@@ -16,15 +16,19 @@ struct lora_hip_demod {
   int device = 0;
   unsigned sf = 0, fft_factor = 0, n = 0, m = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  float2 *d_up = nullptr, *d_down = nullptr, *d_tw = nullptr;   // d_tw: twc then the pass tables
-  size_t tw_off[3] = {0, 0, 0};
+  float2 *d_up = nullptr, *d_down = nullptr;
   float *d_win = nullptr;
+  float2 *d_tw = nullptr;       // twc then the pass tables
+  size_t tw_off[3] = {0, 0, 0};
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
   void *d_desc = nullptr; size_t cap_desc = 0;
   unsigned short *d_idx = nullptr; float *d_val = nullptr; size_t cap_out = 0;
+  unsigned long long *d_dbg = nullptr;   // LORA_STAMPS builds only
   char hip_err[256] = {0};
   const char *kernel_name = "";
+  int num_cu = 256;
+  unsigned blocks_per_cu = LORA_MIN_WAVES;
 };
 
 namespace {
@@ -47,11 +51,12 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
 }
 
 typedef void (*kernel_fn)(const KParams);
-struct Variant { kernel_fn fn; size_t lds; int wpb; const char *name; };
+struct Variant { kernel_fn fn, fn_const; size_t lds; int wpb; const char *name; };
 
 template <int LOGN, int F>
 Variant make_variant(const char *name) {
-  return Variant{&lora_hip::demod_kernel<LOGN, F>, lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN>(), name};
+  return Variant{&lora_hip::demod_kernel<LOGN, F, false>, &lora_hip::demod_kernel<LOGN, F, true>,
+                 lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN>(), name};
 }
 
 #define LORA_VARIANTS_SF(SF) \
@@ -73,8 +78,31 @@ int launch(lora_hip_demod *h, KParams &p) {
   Variant v;
   if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
   if (p.n_win == 0) return LORA_HIP_OK;
-  const unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
-  hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
+  // persistent workgroups: at most blocks_per_cu per CU, each walks the windows grid-stride
+  unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
+  const unsigned resident = (unsigned)h->num_cu * h->blocks_per_cu;
+  if (blocks > resident) blocks = resident;
+#if LORA_STAMPS
+  const size_t ndbg = (size_t)blocks * (lora_hip::kBlock / 64) * 8;
+  if (!h->d_dbg) (void)hipMalloc((void **)&h->d_dbg, (size_t)h->num_cu * 8 * 4 * 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(h->d_dbg, 0, ndbg * sizeof(unsigned long long), h->stream);
+  p.dbg = h->d_dbg;
+#endif
+  // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
+  const bool const_off = (p.desc == nullptr && p.off_step == 0);
+  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
+#if LORA_STAMPS
+  {
+    std::vector<unsigned long long> hd(ndbg);
+    (void)hipMemcpyAsync(hd.data(), h->d_dbg, ndbg * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    double sum[8] = {0};
+    for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
+    const double nw = (double)blocks * (lora_hip::kBlock / 64);
+    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: idle/desc %.0f | load+dechirp %.0f | fft %.0f | magsq %.0f | reduce+store %.0f\n",
+            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+  }
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
   return LORA_HIP_OK;
@@ -187,14 +215,25 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     unsigned long long NS = lora_hip::plan_radix((int)sf, 0);
     for (int ps = 1; ps < NP; ps++) {
       const unsigned long long r = lora_hip::plan_radix((int)sf, ps), L = NS * r;
+      if (tw.size() % 2) tw.push_back(lora_c32{0.f, 0.f});          // keep float4 tables 16-byte aligned
       h->tw_off[ps] = tw.size();
-      for (unsigned rr = 0; rr < F; rr++)
-        for (unsigned long long mm = 1; mm < r; mm++)
-          for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(mm * (n / L) * (F * jm + rr)));
+      const bool small = lora_hip::pass_table_in_lds((int)sf, (int)F, ps);
+      for (unsigned rr = 0; rr < F; rr++) {
+        if (small) {          // float2 [F][r-1][NS]
+          for (unsigned long long mm = 1; mm < r; mm++)
+            for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(mm * (n / L) * (F * jm + rr)));
+        } else {              // float4 [F][2][NS] = { W^1, W^2 } then { W^4, W^8 } of the base twiddle
+          for (unsigned long long h2 = 0; h2 < 2; h2++)
+            for (unsigned long long jm = 0; jm < NS; jm++) {
+              const unsigned long long base_e = (n / L) * (F * jm + rr);
+              tw.push_back(wm((h2 ? 4 : 1) * base_e));
+              tw.push_back(wm((h2 ? 8 : 2) * base_e));
+            }
+        }
+      }
       NS = L;
     }
   }
-
   int rc = LORA_HIP_OK;
   auto fail = [&](int code) { lora_hip_demod_destroy(h); return code; };
   hipError_t e;
@@ -209,9 +248,15 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LORA_HIP_EHIP);
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   // kernels with more than 64 KiB of dynamic LDS need the opt-in
   if (v.lds > 48 * 1024) {
-    if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
       return fail(LORA_HIP_EHIP);
   }
   (void)rc;
@@ -260,6 +305,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   const bool desc_dev = flags & LORA_HIP_DESC_ON_DEVICE;
   if ((flags & LORA_HIP_ASYNC) && ((!iq_dev && !iq_staged) || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
   if (n_win == 0) return LORA_HIP_OK;
+  if (n_samples < h->n) return LORA_HIP_EINVAL;      // the kernel redirects bad windows to sample 0
   HIP_TRY(h, hipSetDevice(h->device));
   int rc;
   // inputs

@@ -27,22 +27,26 @@ struct KParams {
   const float2 *up, *down;      // 2N-entry chirp tables (demod_impl.cc:92-101)
   const float *win;             // N Kaiser taps (demod_impl.cc:85)
   const float2 *twc;            // [F][R]   pass-0 input constants W_(F*R)^(rr*m)           (uniform)
-  const float2 *twp[3];         // per pass ps>=1: [F][r-1][NS] merged twiddles, see fft_pass
+  const void *twp[3];           // per pass ps>=1: merged twiddles, layout chosen by pass_table_in_lds()
   const void *desc;             // lora_win_desc[n_win] or nullptr for the strided form
   unsigned long long pos0, stride;
   unsigned off0, off_step, kind;
   unsigned n_win;
   unsigned short *out_idx;
   float *out_val;
+  unsigned long long *dbg;      // diagnostic builds only (LORA_STAMPS): per-workgroup phase cycle sums
 };
 
 struct WinDesc { unsigned long long pos; unsigned short off; unsigned char kind; unsigned char pad[5]; };
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// complex multiply of the FFT (twiddles): explicit FMA form so that every kernel that shares this
+// code rounds identically, whatever the compiler's contraction heuristics
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
 }
+__device__ __forceinline__ float magsq(float2 a) { return __builtin_fmaf(a.x, a.x, a.y * a.y); }
 // a * (-j)
 __device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }
 
@@ -138,11 +142,51 @@ constexpr int plan_radix(int logn, int ps) {
     default: return 16;   // 12
   }
 }
+constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++) v *= plan_radix(logn, i); return v; }
 
 constexpr int kBlock = 256;
+#ifndef LORA_ABL
+#define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads
+#endif
+#ifndef LORA_STAMPS
+#define LORA_STAMPS 0
+#endif
+#if LORA_STAMPS
+#define LORA_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define LORA_STAMP(i) do { } while (0)
+#endif
+#ifndef LORA_MIN_WAVES
+#define LORA_MIN_WAVES 3
+#endif
+
+// Twiddle table of pass ps >= 1 (merged with the zero-padding twist, see fft_pass).  Vector loads
+// return to the registers at only ~32 B/clk per CU (measured: TD busy 84 % with tables in L2), so
+// per-window table traffic is kept off that path:
+//   small tables live in LDS as float2 [F][r-1][NS]      (copied once per workgroup)
+//   big tables (SF12, SF11/SF10 at high F) stay in L2 as float4 [F][2][NS] holding only the
+//   powers W^1,W^2 | W^4,W^8 of each butterfly's base twiddle; the other powers are products.
+constexpr int kLdsTableBytes = 16384;
+constexpr int pass_entries(int logn, int f, int ps) { return f * (plan_radix(logn, ps) - 1) * plan_ns(logn, ps); }
+constexpr int lds_table_bytes_before(int logn, int f, int ps);
+constexpr bool pass_table_in_lds(int logn, int f, int ps) {
+  return ps > 0 && lds_table_bytes_before(logn, f, ps) + pass_entries(logn, f, ps) * 8 <= kLdsTableBytes;
+}
+constexpr int lds_table_bytes_before(int logn, int f, int ps) {
+  int o = 0;
+  for (int i = 1; i < ps; i++) if (pass_table_in_lds(logn, f, i)) o += pass_entries(logn, f, i) * 8;
+  return o;
+}
+constexpr int pass_lds_offset(int logn, int f, int ps) {   // in float2, inside the LDS table area
+  int o = 0;
+  for (int i = 1; i < ps; i++) if (pass_table_in_lds(logn, f, i)) o += pass_entries(logn, f, i);
+  return o;
+}
 
 // LDS tile padding: one complex of padding per 16 keeps the stride-16 scatter of the first
-// pass conflict-free for ds_write_b64
+// pass conflict-free for ds_write_b64.  Every access is written as pad(thread part) +
+// pad(compile-time part) so that the address is one VGPR plus an immediate; that split is exact
+// because the low four bits of the two parts never carry (see the static_asserts at the uses).
 __device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 4); }
 
 struct Best { float v; int i; };
@@ -164,18 +208,20 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 //     twiddle(ps, rr, jm, m) = W_M^( m * (N/L_ps) * (F*jm + rr) ),  jm = j mod NS, L_ps = NS*r
 // What remains after the last pass is one factor per thread of magnitude 1, which |X|^2 drops.
 template <int LOGN, int F, int PS, int NS>
-__device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const int tw,
-                                         const KParams &p, const int rr) {
+__device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const float2 *lds_tw,
+                                         const int tw, const KParams &p, const int rr) {
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R;
   constexpr int NP = plan_passes(LOGN), r = plan_radix(LOGN, PS), nb = R / r;
   constexpr bool last = (PS == NP - 1);
+  static_assert(T % 16 == 0 || T == 8 || T == 4, "pad split: tw + k*T must not carry out of bit 3");
+  static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
   if constexpr (PS > 0) {
     __syncthreads();                 // previous pass's scatter is visible
 #pragma unroll
-    for (int k = 0; k < R; k++) v[k] = tile[lds_pad(tw + k * T)];
+    for (int k = 0; k < R; k++) v[k] = tile[lds_pad(tw) + lds_pad(k * T)];
     if constexpr (!last) __syncthreads();   // everyone has read before the tile is overwritten
-  } else if constexpr (NP > 1) {
-    if (rr > 0) __syncthreads();     // readers of the previous sub-transform are done
+  } else {
+    __syncthreads();                 // readers of the previous sub-transform / window are done
   }
 #pragma unroll
   for (int q = 0; q < nb; q++) {
@@ -184,140 +230,270 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
 #pragma unroll
     for (int m = 0; m < r; m++) a[m] = v[q + m * nb];
     if constexpr (PS > 0) {
-      const float2 *__restrict__ tp = p.twp[PS] + (rr * (r - 1)) * NS + (j & (NS - 1));
+      const int jm = j & (NS - 1);
+#if LORA_ABL & 4
 #pragma unroll
-      for (int m = 1; m < r; m++) a[m] = cmul(a[m], tp[(m - 1) * NS]);
+      for (int m = 1; m < r; m++) a[m] = cmul(a[m], make_float2(0.6f + m, 0.8f));
+#else
+      if constexpr (pass_table_in_lds(LOGN, F, PS)) {
+        const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + jm;
+#pragma unroll
+        for (int m = 1; m < r; m++) a[m] = cmul(a[m], tp[(m - 1) * NS]);
+      } else {
+        // powers 1,2,4,8 of this butterfly's base twiddle from L2; the rest are products
+        static_assert(r == 8 || r == 16, "power table covers radix 8 and 16");
+        const float4 *__restrict__ tp = reinterpret_cast<const float4 *>(p.twp[PS]) + (rr * 2) * NS + jm;
+        const float4 t0 = tp[0], t1 = tp[NS];
+        float2 w[16];
+        w[1] = make_float2(t0.x, t0.y); w[2] = make_float2(t0.z, t0.w);
+        w[4] = make_float2(t1.x, t1.y); w[8] = make_float2(t1.z, t1.w);
+        w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+        if constexpr (r == 16) {
+#pragma unroll
+          for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
+        }
+#pragma unroll
+        for (int m = 1; m < r; m++) a[m] = cmul(a[m], w[m]);
+      }
+#endif
     }
     Dft<r>::run(a);
     if constexpr (!last) {
       const int o = (j / NS) * NS * r + (j & (NS - 1));
 #pragma unroll
-      for (int m = 0; m < r; m++) tile[lds_pad(o + m * NS)] = a[m];
+      for (int m = 0; m < r; m++) tile[lds_pad(o) + lds_pad(m * NS)] = a[m];
     } else {
 #pragma unroll
       for (int m = 0; m < r; m++) v[q + m * nb] = a[m];
     }
   }
-  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, tw, p, rr);
+  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr);
 }
 
 template <int LOGN, int F>
-__global__ __launch_bounds__(kBlock, 2) void demod_kernel(const KParams p) {
+constexpr int demod_lds_table_entries() { return pass_lds_offset(LOGN, F, plan_passes(LOGN)); }
+
+// Everything the kernel needs to know about one window, resolved one iteration ahead.
+struct WinCtx {
+  unsigned long long pos;
+  unsigned win_id, off, kind;
+  bool valid, in_range;
+};
+
+template <int N>
+__device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned win_id) {
+  WinCtx c;
+  c.win_id = win_id;
+  c.valid = win_id < p.n_win;
+  unsigned off, kind;
+  if (p.desc != nullptr) {
+    const WinDesc d = c.valid ? reinterpret_cast<const WinDesc *>(p.desc)[win_id] : WinDesc{0, 0, 0, {0}};
+    c.pos = d.pos; off = d.off; kind = d.kind;
+  } else {
+    c.pos = p.pos0 + (unsigned long long)win_id * p.stride;
+    off = (p.off0 + win_id * p.off_step) & (N - 1);
+    kind = p.kind;
+  }
+  // guard: never read outside the capture or the tables.  An invalid window is redirected to
+  // sample 0 (the host guarantees n_samples >= N) and reported as (0xFFFF, -1).
+  c.in_range = c.valid && off < (unsigned)N && kind <= 1u &&
+               c.pos <= p.n_samples && p.n_samples - c.pos >= (unsigned long long)N;
+  if (!c.in_range) { c.pos = 0; off = 0; kind = 0; }
+  c.off = off; c.kind = kind;
+  return c;
+}
+
+// Persistent workgroups: each walks the windows grid-stride (WPB windows per iteration), software
+// pipelined so that a wave never waits on HBM with nothing else to do:
+//   * the raw IQ of window i+1 is loaded into registers while the last sub-transform of window i
+//     runs (its registers are those of x, dead by then);
+//   * CONST_OFF (strided sweep with one chirp offset: the steady-state path): the chirp and
+//     Kaiser taps of a thread are the same for every window, loaded once, kept in VGPRs;
+//   * otherwise they are requested first thing in iteration i, and the reduction + store of
+//     window i-1 runs while they are in flight.
+template <int LOGN, int F, bool CONST_OFF>
+__global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KParams p) {
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R, WPB = kBlock / T;
   constexpr int PADN = N + N / 16;
   static_assert(T >= 1 && T <= kBlock && WPB >= 1, "geometry");
+  static_assert(plan_radix(LOGN, 0) == R, "pass 0 must consume all of a thread's points");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *smem = reinterpret_cast<float2 *>(smem_raw);
-  // second region: per-wave partial results for windows spanning several waves
-  Best *red = reinterpret_cast<Best *>(smem + WPB * PADN);
+  float2 *lds_tw = smem + WPB * PADN;
+  // per-wave partial results for windows spanning several waves
+  Best *red = reinterpret_cast<Best *>(lds_tw + demod_lds_table_entries<LOGN, F>());
 
   const int tid = threadIdx.x;
   const int tw = tid % T;          // thread within its window
   const int wl = tid / T;          // window within the workgroup
-  const unsigned win_id = blockIdx.x * WPB + wl;
   float2 *tile = smem + wl * PADN;
 
-  // window descriptor
-  unsigned long long pos; unsigned off, kind;
-  bool valid = win_id < p.n_win;
-  if (p.desc != nullptr) {
-    const WinDesc d = valid ? reinterpret_cast<const WinDesc *>(p.desc)[win_id] : WinDesc{0, 0, 0, {0}};
-    pos = d.pos; off = d.off; kind = d.kind;
-  } else {
-    pos = p.pos0 + (unsigned long long)win_id * p.stride;
-    off = (p.off0 + win_id * p.off_step) & (N - 1);
-    kind = p.kind;
-  }
-  // guard: never read outside the capture or the 2N-entry tables
-  const bool in_range = valid && off < (unsigned)N && pos <= p.n_samples && p.n_samples - pos >= (unsigned long long)N;
-
-  // ---- load + dechirp + window: x[k] <-> sample n = tw + k*T ----------------------------
-  float2 x[R];
-  {
-    const float2 *src = p.iq + (in_range ? pos : 0ull);
-    const float2 *chirp = (kind == 0 ? p.down : p.up) + (in_range ? off : 0u);
+  // once per workgroup: small twiddle tables -> LDS (visible after the first barrier of pass 0)
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-      const int n = tw + k * T;
-      float2 s = make_float2(0.f, 0.f), c = make_float2(0.f, 0.f);
-      float w = 1.0f;
-      if (in_range) {
-        s = src[n];
-        c = chirp[n];
-        if (kind == 0) w = p.win[n];
+  for (int ps = 1; ps < plan_passes(LOGN); ps++) {
+    if (pass_table_in_lds(LOGN, F, ps)) {
+      const float2 *__restrict__ g = reinterpret_cast<const float2 *>(p.twp[ps]);
+      for (int i = tid; i < pass_entries(LOGN, F, ps); i += kBlock) lds_tw[pass_lds_offset(LOGN, F, ps) + i] = g[i];
+    }
+  }
+
+#if LORA_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+  // reduction over the T threads of a window + store: deferred to the next iteration
+  auto finish = [&](const WinCtx &w, Best best, const bool bin0_nan) {
+    constexpr int LANES = T < 64 ? T : 64;
+#pragma unroll
+    for (int s = LANES / 2; s >= 1; s >>= 1) {
+      Best o;
+      o.v = __shfl_xor(best.v, s, 64);
+      o.i = __shfl_xor(best.i, s, 64);
+      best = better(best, o);
+    }
+    if (T > 64) {
+      constexpr int WPW = T / 64 > 0 ? T / 64 : 1;   // waves per window
+      const int wave = tid / 64, lane = tid & 63;
+      if (lane == 0) red[wave] = best;
+      __syncthreads();
+      if (tw == 0) {
+        Best b = red[wl * WPW];
+#pragma unroll
+        for (int ww = 1; ww < WPW; ww++) b = better(b, red[wl * WPW + ww]);
+        best = b;
       }
-      float2 t = cmul_volk(s, c);                                     // :179/:183/:310
-      if (kind == 0) t = make_float2(__fmul_rn(t.x, w), __fmul_rn(t.y, w));   // :192
-      x[k] = t;
+      // red[] is rewritten one whole window later, behind that window's pass barriers
     }
-  }
-
-  Best best = {-1.0f, 0};
-  bool bin0_nan = false;
-
-#pragma nounroll
-  for (int rr = 0; rr < F; rr++) {
-    float2 v[R];
-    // decimation in frequency by F: bins F*k + rr come from x[n] * exp(-2 pi i rr n / M)
-    static_assert(plan_radix(LOGN, 0) == R, "pass 0 must consume all of a thread's points");
-    if (rr == 0) {
-#pragma unroll
-      for (int k = 0; k < R; k++) v[k] = x[k];
-    } else {
-      const float2 *__restrict__ tc = p.twc + rr * R;     // wave-uniform -> scalar loads
-      v[0] = x[0];
-#pragma unroll
-      for (int k = 1; k < R; k++) v[k] = cmul(x[k], tc[k]);
+    if (tw == 0 && w.valid) {
+      unsigned short oi; float ov;
+      if (!w.in_range) { oi = 0xFFFFu; ov = -1.0f; }
+      else if (bin0_nan) { oi = 0; ov = __builtin_nanf(""); }   // magsq[0] NaN: nothing ever compares greater
+      else { oi = (unsigned short)best.i; ov = best.v; }
+      p.out_idx[w.win_id] = oi;
+      p.out_val[w.win_id] = ov;
     }
+  };
 
-    fft_pass<LOGN, F, 0, 1>(v, tile, tw, p, rr);
-    // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
-    // lowest index of this thread's maximum for this rr
-    Best b = {-1.0f, 0};
+  const unsigned step = gridDim.x * WPB;
+  WinCtx cur = window_ctx<N>(p, blockIdx.x * WPB + wl);
+  // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
+  float2 cc[CONST_OFF ? R : 1];
+  float cwin[CONST_OFF ? R : 1];
+  if constexpr (CONST_OFF) {
+    const float2 *__restrict__ chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
+    const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-      const float mag = v[k].x * v[k].x + v[k].y * v[k].y;
-      if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);
-      if (mag > b.v) { b.v = mag; b.i = F * (tw + k * T) + rr; }
+      cc[k] = chirp[k * T];
+      const float wk = wsrc[k * T];
+      cwin[k] = (p.kind == 0) ? wk : 1.0f;
     }
-    best = (rr == 0) ? b : better(best, b);
   }
+  float2 nx[R];                    // raw IQ of the window about to be processed: sample tw + k*T
+  {
+    const float2 *__restrict__ src = p.iq + cur.pos + tw;
+#pragma unroll
+    for (int k = 0; k < R; k++) nx[k] = src[k * T];
+  }
+  WinCtx prev = cur;
+  Best prev_best = {-1.0f, 0};
+  bool prev_nan = false, have_prev = false;
 
-  // ---- reduce over the T threads of the window --------------------------------------------
-  constexpr int LANES = T < 64 ? T : 64;
+  for (unsigned base = blockIdx.x * WPB; base < p.n_win; base += step) {
+    LORA_STAMP(0);
+    // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
+    float2 c[R];
+    float w[R];
+    if constexpr (CONST_OFF) {
 #pragma unroll
-  for (int s = LANES / 2; s >= 1; s >>= 1) {
-    Best o;
-    o.v = __shfl_xor(best.v, s, 64);
-    o.i = __shfl_xor(best.i, s, 64);
-    best = better(best, o);
-  }
-  if (T > 64) {
-    constexpr int WPW = T / 64 > 0 ? T / 64 : 1;   // waves per window
-    const int wave = tid / 64, lane = tid & 63;
-    if (lane == 0) red[wave] = best;
-    __syncthreads();
-    if (tw == 0) {
-      Best b = red[wl * WPW];
+      for (int k = 0; k < R; k++) { c[k] = cc[k]; w[k] = cwin[k]; }
+    } else {
+      const float2 *__restrict__ chirp = (cur.kind == 0 ? p.down : p.up) + cur.off + tw;
+      const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
-      for (int w = 1; w < WPW; w++) b = better(b, red[wl * WPW + w]);
-      best = b;
+      for (int k = 0; k < R; k++) {
+#if LORA_ABL & 2
+        c[k] = make_float2(0.5f, tw * 0.001f); w[k] = 0.3f;
+#else
+        c[k] = chirp[k * T];
+        const float wk = wsrc[k * T];
+        w[k] = (cur.kind == 0) ? wk : 1.0f;            // t*1.0f == t bit for bit (the SFD path has no window)
+#endif
+      }
     }
+    if (have_prev) finish(prev, prev_best, prev_nan);
+    LORA_STAMP(4);    // reduction + store of the previous window
+    const WinCtx nxt = window_ctx<N>(p, cur.win_id + step);
+
+    // ---- dechirp + window: x[k] <-> sample n = tw + k*T -----------------------------------
+    float2 x[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const float2 t = cmul_volk(nx[k], c[k]);                             // :179/:183/:310
+      x[k] = make_float2(__fmul_rn(t.x, w[k]), __fmul_rn(t.y, w[k]));      // :192
+    }
+    LORA_STAMP(1);    // operands landed + dechirp
+
+    Best best = {-1.0f, 0};
+    bool bin0_nan = false;
+#pragma unroll
+    for (int rr = 0; rr < F; rr++) {
+      float2 v[R];
+      // decimation in frequency by F: bins F*k + rr come from x[n] * exp(-2 pi i rr n / M)
+      if (rr == 0) {
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = x[k];
+      } else {
+        const float2 *__restrict__ tc = p.twc + rr * R;     // wave-uniform -> scalar loads
+        v[0] = x[0];
+#pragma unroll
+        for (int k = 1; k < R; k++) v[k] = cmul(x[k], tc[k]);
+      }
+      if (rr == F - 1) {
+        // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
+        asm volatile("" ::: "memory");
+        const float2 *__restrict__ src = p.iq + nxt.pos + tw;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+#if LORA_ABL & 1
+          nx[k] = make_float2(1.0f + tw, k);
+#else
+          nx[k] = src[k * T];
+#endif
+        }
+      }
+      fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
+      LORA_STAMP(2);  // all passes of this sub-transform
+      // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
+      // lowest index of this thread's maximum for this rr
+      Best b = {-1.0f, 0};
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const float mag = magsq(v[k]);
+        if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);
+        if (mag > b.v) { b.v = mag; b.i = F * (tw + k * T) + rr; }
+      }
+      best = (rr == 0) ? b : better(best, b);
+      LORA_STAMP(3);  // |X|^2 + per-thread argmax
+      asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
+    }
+    prev = cur; prev_best = best; prev_nan = bin0_nan; have_prev = true;
+    cur = nxt;
   }
-  if (tw == 0 && valid) {
-    unsigned short oi; float ov;
-    if (!in_range) { oi = 0xFFFFu; ov = -1.0f; }
-    else if (bin0_nan) { oi = 0; ov = __builtin_nanf(""); }   // magsq[0] NaN: nothing ever compares greater
-    else { oi = (unsigned short)best.i; ov = best.v; }
-    p.out_idx[win_id] = oi;
-    p.out_val[win_id] = ov;
+  if (have_prev) finish(prev, prev_best, prev_nan);
+#if LORA_STAMPS
+  if (p.dbg && (tid & 63) == 0) {
+    for (int i = 0; i < 8; i++) p.dbg[(blockIdx.x * (kBlock / 64) + tid / 64) * 8 + i] = stamp_acc[i];
   }
+#endif
 }
 
 template <int LOGN, int F>
 constexpr size_t demod_lds_bytes() {
   constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
-  return (size_t)WPB * PADN * sizeof(float2) + (kBlock / 64) * sizeof(Best);
+  return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
+         (kBlock / 64) * sizeof(Best);
 }
 template <int LOGN>
 constexpr int demod_wpb() { return kBlock / ((1 << LOGN) / plan_points(LOGN)); }
