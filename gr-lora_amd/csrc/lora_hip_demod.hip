@@ -99,8 +99,8 @@ int launch(lora_hip_demod *h, KParams &p) {
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
     const double nw = (double)blocks * (lora_hip::kBlock / 64);
-    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: idle/desc %.0f | load+dechirp %.0f | fft %.0f | magsq %.0f | reduce+store %.0f\n",
-            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f\n",
+            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw);
   }
 #endif
   hipError_t e = hipGetLastError();

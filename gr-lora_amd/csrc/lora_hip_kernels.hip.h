@@ -209,19 +209,28 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 // What remains after the last pass is one factor per thread of magnitude 1, which |X|^2 drops.
 template <int LOGN, int F, int PS, int NS>
 __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const float2 *lds_tw,
-                                         const int tw, const KParams &p, const int rr) {
+                                         const int tw, const KParams &p, const int rr
+#if LORA_STAMPS
+                                         , unsigned long long (&stamp_acc)[8], unsigned long long &stamp_last
+#endif
+                                         ) {
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R;
   constexpr int NP = plan_passes(LOGN), r = plan_radix(LOGN, PS), nb = R / r;
   constexpr bool last = (PS == NP - 1);
   static_assert(T % 16 == 0 || T == 8 || T == 4, "pad split: tw + k*T must not carry out of bit 3");
   static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
+  LORA_STAMP(2);                     // compute (butterflies, scatter) since the last stamp
   if constexpr (PS > 0) {
     __syncthreads();                 // previous pass's scatter is visible
+    LORA_STAMP(5);                   // barrier wait
 #pragma unroll
     for (int k = 0; k < R; k++) v[k] = tile[lds_pad(tw) + lds_pad(k * T)];
+    LORA_STAMP(6);                   // LDS gather latency
     if constexpr (!last) __syncthreads();   // everyone has read before the tile is overwritten
+    LORA_STAMP(5);
   } else {
     __syncthreads();                 // readers of the previous sub-transform / window are done
+    LORA_STAMP(5);
   }
 #pragma unroll
   for (int q = 0; q < nb; q++) {
@@ -267,7 +276,11 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
       for (int m = 0; m < r; m++) v[q + m * nb] = a[m];
     }
   }
+#if LORA_STAMPS
+  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr, stamp_acc, stamp_last);
+#else
   if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr);
+#endif
 }
 
 template <int LOGN, int F>
@@ -463,7 +476,11 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
         }
       }
+#if LORA_STAMPS
+      fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr, stamp_acc, stamp_last);
+#else
       fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
+#endif
       LORA_STAMP(2);  // all passes of this sub-transform
       // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
       // lowest index of this thread's maximum for this rr
