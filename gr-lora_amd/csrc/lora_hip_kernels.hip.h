@@ -355,8 +355,11 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
 
-  // reduction over the T threads of a window + store: deferred to the next iteration
-  auto finish = [&](const WinCtx &w, Best best, const bool bin0_nan) {
+  // Reduction over the T threads of a window.  Part 1 (end of window i): wave64 shuffles, then one
+  // partial per wave into red[i & 1][wave] -- no barrier.  Part 2 (inside window i+1, after its
+  // first pass barriers): thread 0 of the window combines the partials and stores (idx, max).
+  // The two red[] halves alternate, so a half is rewritten two windows later, behind barriers.
+  auto reduce_partial = [&](Best best, const int par) -> Best {
     constexpr int LANES = T < 64 ? T : 64;
 #pragma unroll
     for (int s = LANES / 2; s >= 1; s >>= 1) {
@@ -366,25 +369,27 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       best = better(best, o);
     }
     if (T > 64) {
-      constexpr int WPW = T / 64 > 0 ? T / 64 : 1;   // waves per window
-      const int wave = tid / 64, lane = tid & 63;
-      if (lane == 0) red[wave] = best;
-      __syncthreads();
-      if (tw == 0) {
-        Best b = red[wl * WPW];
+      if ((tid & 63) == 0) red[par * (kBlock / 64) + tid / 64] = best;
+    }
+    return best;
+  };
+  auto combine_store = [&](const WinCtx &w, Best best, const bool bin0_nan, const int par) {
+    if (tw == 0) {
+      if (T > 64) {
+        constexpr int WPW = T / 64 > 0 ? T / 64 : 1;   // waves per window
+        Best b = red[par * (kBlock / 64) + wl * WPW];
 #pragma unroll
-        for (int ww = 1; ww < WPW; ww++) b = better(b, red[wl * WPW + ww]);
+        for (int ww = 1; ww < WPW; ww++) b = better(b, red[par * (kBlock / 64) + wl * WPW + ww]);
         best = b;
       }
-      // red[] is rewritten one whole window later, behind that window's pass barriers
-    }
-    if (tw == 0 && w.valid) {
-      unsigned short oi; float ov;
-      if (!w.in_range) { oi = 0xFFFFu; ov = -1.0f; }
-      else if (bin0_nan) { oi = 0; ov = __builtin_nanf(""); }   // magsq[0] NaN: nothing ever compares greater
-      else { oi = (unsigned short)best.i; ov = best.v; }
-      p.out_idx[w.win_id] = oi;
-      p.out_val[w.win_id] = ov;
+      if (w.valid) {
+        unsigned short oi; float ov;
+        if (!w.in_range) { oi = 0xFFFFu; ov = -1.0f; }
+        else if (bin0_nan) { oi = 0; ov = __builtin_nanf(""); }   // magsq[0] NaN: nothing ever compares greater
+        else { oi = (unsigned short)best.i; ov = best.v; }
+        p.out_idx[w.win_id] = oi;
+        p.out_val[w.win_id] = ov;
+      }
     }
   };
 
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
   WinCtx prev = cur;
   Best prev_best = {-1.0f, 0};
   bool prev_nan = false, have_prev = false;
+  int par = 0;
 
   for (unsigned base = blockIdx.x * WPB; base < p.n_win; base += step) {
     LORA_STAMP(0);
@@ -435,8 +441,6 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
       }
     }
-    if (have_prev) finish(prev, prev_best, prev_nan);
-    LORA_STAMP(4);    // reduction + store of the previous window
     const WinCtx nxt = window_ctx<N>(p, cur.win_id + step);
 
     // ---- dechirp + window: x[k] <-> sample n = tw + k*T -----------------------------------
@@ -482,6 +486,8 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
 #endif
       LORA_STAMP(2);  // all passes of this sub-transform
+      if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
+      LORA_STAMP(4);
       // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
       // lowest index of this thread's maximum for this rr
       Best b = {-1.0f, 0};
@@ -495,10 +501,15 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
       asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
     }
-    prev = cur; prev_best = best; prev_nan = bin0_nan; have_prev = true;
+    prev_best = reduce_partial(best, par);
+    prev = cur; prev_nan = bin0_nan; have_prev = true;
     cur = nxt;
+    par ^= 1;
   }
-  if (have_prev) finish(prev, prev_best, prev_nan);
+  if (have_prev) {
+    if (T > 64) __syncthreads();
+    combine_store(prev, prev_best, prev_nan, par ^ 1);
+  }
 #if LORA_STAMPS
   if (p.dbg && (tid & 63) == 0) {
     for (int i = 0; i < 8; i++) p.dbg[(blockIdx.x * (kBlock / 64) + tid / 64) * 8 + i] = stamp_acc[i];
@@ -510,7 +521,7 @@ template <int LOGN, int F>
 constexpr size_t demod_lds_bytes() {
   constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
   return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
-         (kBlock / 64) * sizeof(Best);
+         2 * (kBlock / 64) * sizeof(Best);
 }
 template <int LOGN>
 constexpr int demod_wpb() { return kBlock / ((1 << LOGN) / plan_points(LOGN)); }
