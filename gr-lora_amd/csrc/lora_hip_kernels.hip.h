@@ -156,6 +156,9 @@ constexpr int kBlock = 256;
 #else
 #define LORA_STAMP(i) do { } while (0)
 #endif
+#ifndef LORA_SF12_DIGITS
+#define LORA_SF12_DIGITS 1
+#endif
 #ifndef LORA_MIN_WAVES
 #define LORA_MIN_WAVES 3
 #endif
@@ -285,6 +288,67 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
 
 template <int LOGN, int F>
 constexpr int demod_lds_table_entries() { return pass_lds_offset(LOGN, F, plan_passes(LOGN)); }
+
+// SF12 (16 x 16 x 16, one window per workgroup): the same three radix-16 passes with the data
+// mapped by digits instead of the generic Stockham scatter.  n = 256*n2 + 16*n1 + n0,
+// k = ka + 16*kb + 256*kc, thread = (hi, lo) = (tw >> 4, tw & 15), 4 values of hi per wave:
+//   pass 0: thread (n1, n0) transforms n2 -> ka          exchange 1: all waves, tile[ka][n1][n0]
+//   pass 1: thread (ka, n0) transforms n1 -> kb          exchange 2: inside each 16-lane row
+//   pass 2: thread (ka, kb) transforms n0 -> kc          bin = ka + 16*kb + 256*kc
+// After exchange 1 a wave reads exactly the four rows ka = 4w..4w+3 of the tile and nobody else
+// does, so exchange 2 reuses those rows with wave-local ordering only (DS operations of one wave
+// execute in order): two workgroup barriers per transform instead of four.  Rows are 272 = 16*17
+// elements long: conflict-free for the row-contiguous accesses of exchange 1 and for the
+// stride-17 transpose of exchange 2.
+template <int F>
+__device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const float2 *lds_tw, const int tw,
+                                         const KParams &p, const int rr) {
+  static_assert(pass_table_in_lds(12, F, 1) && !pass_table_in_lds(12, F, 2), "table placement assumed below");
+  constexpr int ROW = 272;
+  const int hi = tw >> 4, lo = tw & 15;
+  Dft<16>::run(v);                                   // n2 -> ka
+  __syncthreads();                                   // every wave is done with the previous transform's rows
+  {
+    float2 *o = tile + tw;
+#pragma unroll
+    for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
+  }
+  __syncthreads();
+  {
+    const float2 *i = tile + hi * ROW + lo;
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = i[m * 16];   // thread (ka = hi, n0 = lo), register n1 = m
+  }
+  {
+    const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
+#pragma unroll
+    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tp[(m - 1) * 16]);
+  }
+  Dft<16>::run(v);                                   // n1 -> kb
+  {
+    float2 *o = tile + hi * ROW + lo;
+#pragma unroll
+    for (int m = 0; m < 16; m++) o[m * 17] = v[m];   // own row: [kb = m][n0 = lo], wave-local
+    const float2 *i = tile + hi * ROW + lo * 17;
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = i[m];        // thread (ka = hi, kb = lo), register n0 = m
+  }
+  {
+    // powers 1,2,4,8 of this butterfly's base twiddle W_M^(F*g + rr), g = ka + 16*kb
+    const int g = hi + 16 * lo;
+    const float4 *__restrict__ tp = reinterpret_cast<const float4 *>(p.twp[2]) + (rr * 2) * 256 + g;
+    const float4 t0 = tp[0], t1 = tp[256];
+    float2 w[16];
+    w[1] = make_float2(t0.x, t0.y); w[2] = make_float2(t0.z, t0.w);
+    w[4] = make_float2(t1.x, t1.y); w[8] = make_float2(t1.z, t1.w);
+    w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+#pragma unroll
+    for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
+#pragma unroll
+    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], w[m]);
+  }
+  Dft<16>::run(v);                                   // n0 -> kc: v[kc] is bin g + 256*kc
+}
 
 // Everything the kernel needs to know about one window, resolved one iteration ahead.
 struct WinCtx {
@@ -483,7 +547,8 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #if LORA_STAMPS
       fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr, stamp_acc, stamp_last);
 #else
-      fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
+      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, p, rr);
+      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
 #endif
       LORA_STAMP(2);  // all passes of this sub-transform
       if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
@@ -494,8 +559,10 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const float mag = magsq(v[k]);
-        if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);
-        if (mag > b.v) { b.v = mag; b.i = F * (tw + k * T) + rr; }
+        if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);      // thread 0 holds bin 0 in both mappings
+        // bin held by register k: generic Stockham tw + k*T; SF12 digit mapping (tw>>4) + 16*(tw&15) + 256*k
+        const int kout = (LOGN == 12 && LORA_SF12_DIGITS && !LORA_STAMPS) ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
+        if (mag > b.v) { b.v = mag; b.i = F * kout + rr; }
       }
       best = (rr == 0) ? b : better(best, b);
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
