@@ -187,6 +187,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   Variant v;
   pick_variant(sf, fft_factor, &v);
   h->kernel_name = v.name;
+  if (const char *e = getenv("LORA_HIP_BLOCKS_PER_CU")) { int b = atoi(e); if (b >= 1 && b <= 8) h->blocks_per_cu = (unsigned)b; }   // tuning knob
 
   const size_t n = h->n, m = h->m;
   std::vector<lora_c32> up(2 * n), down(2 * n);

@@ -1,0 +1,163 @@
+"""GPU parity at full size through size-independent properties, plus the edge cases of the C ABI.
+Everything goes through the C ABI (gr-lora_amd/capi.py -> liblora_hip_demod.so)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gr_lora_amd
+    return gr_lora_amd
+
+
+@pytest.mark.parametrize("sf,f", [(7, 1), (8, 2), (9, 4), (10, 2), (11, 2), (12, 1), (12, 2), (12, 4)])
+def test_pure_tone_lands_in_its_bin(sf, f, g):
+    """x[n] = conj(downchirp[off+n]) * exp(2 pi i b n / N): after the dechirp this is a pure tone in
+    bin b of the N-point grid, i.e. bin F*b of the padded spectrum; its power is (sum of taps)^2."""
+    n = 1 << sf
+    up, down = oracle.chirp_tables(sf)
+    w = oracle.kaiser(n, cases.BETA).astype(np.float64)
+    h = g.HipDemod(sf, f, cases.BETA)
+    rng = np.random.default_rng(sf * 10 + f)
+    bins = rng.integers(0, n, 64)
+    offs = (rng.integers(0, 16, 64) * (n // 16)).astype(np.int64)
+    k = np.arange(n)
+    iq = np.concatenate([np.conj(down[o:o + n].astype(np.complex128)) * np.exp(2j * np.pi * b * k / n)
+                         for b, o in zip(bins, offs)]).astype(np.complex64)
+    desc = g.make_desc(np.arange(64, dtype=np.uint64) * n, offs.astype(np.uint16), g.capi.WIN_UP)
+    idx, val = h.batch(iq, desc)
+    assert np.array_equal(idx, (f * bins).astype(np.uint16))
+    assert np.allclose(val, w.sum() ** 2, rtol=2e-4)
+    h.close()
+
+
+@pytest.mark.parametrize("sf,f", [(8, 2), (10, 4), (12, 2)])
+def test_scaling_and_sfd_kind(sf, f, g):
+    """|X|^2 is homogeneous of degree 2 (power-of-two gains are exact in floating point, so the argmax
+    and the scaled maximum must be bit-identical); an SFD window of an up-chirp-free down-chirp is DC."""
+    n = 1 << sf
+    cap, _, _ = cases.make_capture(sf, [10], seed=5 + sf, snr_db=3)
+    h = g.HipDemod(sf, f, cases.BETA)
+    count = len(cap) // n
+    i1, v1 = h.batch_strided(cap, 0, n, count)
+    i2, v2 = h.batch_strided((cap * np.float32(4.0)).astype(np.complex64), 0, n, count)
+    assert np.array_equal(i1, i2) and np.array_equal(v2, v1 * np.float32(16.0))
+    up, down = oracle.chirp_tables(sf)
+    i3, v3 = h.batch_strided(np.ascontiguousarray(down[:n]), 0, n, 1, kind=g.capi.WIN_SFD)
+    assert i3[0] == 0 and abs(v3[0] - n * n) <= 1e-4 * n * n        # down*up == 1 -> all energy in bin 0
+    h.close()
+
+
+@pytest.mark.parametrize("sf,f", [(12, 2), (10, 2), (7, 4)])
+def test_full_size_sweep_matches_oracle_on_a_sample(sf, f, g):
+    """BASELINE-sized launch (>= 64 MiB of IQ resident in HBM): the whole sweep must equal the
+    descriptor form bit for bit, and a random sample of windows must match the oracle."""
+    import torch
+    n = 1 << sf
+    count = (64 << 20) // (8 * n)
+    rng = np.random.default_rng(1234 + sf)
+    cap, _, _ = cases.make_capture(sf, [24, 40], seed=77 + sf, snr_db=0)
+    reps = -(-count * n // len(cap))
+    iq = np.tile(cap, reps)[:count * n]
+    dev = torch.device("cuda:0")
+    t_iq = torch.from_numpy(iq).to(dev)
+    oi = torch.empty(count, dtype=torch.int16, device=dev); ov = torch.empty(count, dtype=torch.float32, device=dev)
+    h = g.HipDemod(sf, f, cases.BETA)
+    h.batch_strided(t_iq, 0, n, count, chirp_off=n // 4, out_idx=oi, out_val=ov)
+    idx = oi.cpu().numpy().view(np.uint16); val = ov.cpu().numpy()
+    # periodicity: the tiled capture repeats every len(cap) samples; windows one period apart see
+    # the same samples whenever the period is a multiple of N
+    if len(cap) % n == 0:
+        per = len(cap) // n
+        assert np.array_equal(idx[:count - per], idx[per:]) and np.array_equal(val[:count - per], val[per:])
+    pick = np.sort(rng.choice(count, 256, replace=False)).astype(np.uint64)
+    d = oracle.Demod(sf, False, cases.BETA, f)
+    ri, rv, rm = d.window_argmax(iq, pick * n, n // 4, oracle.KIND_UP)
+    gi, gv = idx[pick.astype(np.int64)], val[pick.astype(np.int64)]
+    assert np.max(np.abs(gv - rv) / rv) <= 1e-4
+    decided = rm > 1e-4
+    assert np.array_equal(gi[decided], ri[decided]) and decided.sum() > 200
+    # descriptor form on the same sample: bit-identical to the sweep
+    di, dv = h.batch(t_iq, g.make_desc(pick * n, n // 4, g.capi.WIN_UP))
+    assert np.array_equal(di, gi) and np.array_equal(dv, gv)
+    h.close()
+
+
+def test_nan_and_inf_follow_the_reference_scan(g):
+    """demod_impl::argmax (:118-131): max_val starts at magsq[0] and only strict '>' replaces it, so a NaN
+    in bin 0 gives (0, NaN); NaNs elsewhere never win; +inf wins at its lowest bin."""
+    sf, f, n = 7, 2, 128
+    h = g.HipDemod(sf, f, cases.BETA)
+    d = oracle.Demod(sf, False, cases.BETA, f)
+    x = np.zeros(3 * n, np.complex64)
+    x[:n] = np.nan                                   # every bin NaN -> bin 0 NaN
+    x[n:2 * n] = 1.0; x[n + 5] = np.inf              # inf input -> inf/NaN spectrum
+    x[2 * n:] = (np.arange(n) % 7).astype(np.float32)
+    idx, val = h.batch_strided(x, 0, n, 3)
+    ri, rv, _ = d.window_argmax(x, [0, n, 2 * n], 0, oracle.KIND_UP, want_margin=False)
+    assert idx[0] == 0 and np.isnan(val[0]) and ri[0] == 0 and np.isnan(rv[0])
+    assert idx[2] == ri[2] and abs(val[2] - rv[2]) <= 1e-4 * rv[2]
+    # window 1: the oracle's and the GPU's FFT orders differ, so only the class of the result is compared
+    assert (np.isnan(val[1]) or np.isinf(val[1])) and (np.isnan(rv[1]) or np.isinf(rv[1]))
+    h.close()
+
+
+def test_abi_argument_checking_on_gpu(g):
+    import torch
+    sf, n = 8, 256
+    h = g.HipDemod(sf, 2, cases.BETA)
+    iq = np.zeros(4 * n, np.complex64)
+    idx, val = h.batch_strided(iq, 0, n, 0)                       # empty batch is fine
+    assert len(idx) == 0
+    with pytest.raises(g.LoraHipError) as e:
+        h.batch_strided(iq, n, n, 4)                              # last window runs past the capture
+    assert e.value.code == g.capi.EINVAL
+    with pytest.raises(g.LoraHipError):
+        h.batch_strided(iq, 0, n, 1, chirp_off=n)                 # chirp offset outside the table
+    with pytest.raises(g.LoraHipError):
+        h.batch(iq, g.make_desc([3 * n + 1], 0, 0))               # descriptor past the capture
+    with pytest.raises(g.LoraHipError):
+        h.batch(iq[:n - 1], g.make_desc([0], 0, 0))               # capture shorter than one window
+    # device-resident descriptors cannot be validated on the host: the kernel guards them and
+    # reports (0xFFFF, -1) without touching memory out of range
+    dev = torch.device("cuda:0")
+    desc = g.make_desc([0, 4 * n - 1, 1 << 40, n], [0, 0, 0, 3 * n], [0, 0, 0, 0])
+    t_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    t_iq = torch.from_numpy(iq).to(dev)
+    oi = torch.zeros(4, dtype=torch.int16, device=dev); ov = torch.zeros(4, dtype=torch.float32, device=dev)
+    lib = g.capi.lib()
+    rc = lib.lora_hip_demod_batch(h._h, t_iq.data_ptr(), len(iq), t_desc.data_ptr(), 4, oi.data_ptr(), ov.data_ptr(),
+                                  g.capi.IQ_ON_DEVICE | g.capi.DESC_ON_DEVICE | g.capi.OUT_ON_DEVICE)
+    assert rc == 0
+    assert list(oi.cpu().numpy().view(np.uint16)) == [0, 0xFFFF, 0xFFFF, 0xFFFF]
+    assert list(ov.cpu().numpy()) == [0.0, -1.0, -1.0, -1.0]
+    with pytest.raises(g.LoraHipError) as e:
+        g.HipDemod(sf, 3, cases.BETA)
+    assert e.value.code == g.capi.EUNSUPPORTED
+    h.close()
+
+
+def test_random_sweep_cfg3(g):
+    """BASELINE config 3 in small: SF7-12 x F{1,2,4} x SNR{-20..10}, every stride-N window against the oracle."""
+    total = flips = 0
+    for sf in range(7, 13):
+        n = 1 << sf
+        for f in (1, 2, 4):
+            h = g.HipDemod(sf, f, cases.BETA)
+            d = oracle.Demod(sf, False, cases.BETA, f)
+            for si, snr in enumerate((-20, -10, 0, 10)):
+                cap, _, _ = cases.make_capture(sf, [6], seed=1000 * sf + 10 * f + si, snr_db=snr)
+                count = len(cap) // n
+                gi, gv = h.batch_strided(cap, 0, n, count)
+                ri, rv, rm = d.window_argmax(cap, np.arange(count, dtype=np.uint64) * n, 0, oracle.KIND_UP)
+                assert np.max(np.abs(gv - rv) / rv) <= 1e-4, (sf, f, snr)
+                decided = rm > 1e-4
+                assert np.array_equal(gi[decided], ri[decided]), (sf, f, snr)
+                total += count; flips += int(np.count_nonzero(gi != ri))
+            h.close()
+    print(f"cfg3 sweep: {total} windows, {flips} sub-margin argmax differences")
