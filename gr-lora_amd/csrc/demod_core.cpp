@@ -4,7 +4,9 @@
 // the result (lib/demod_impl.cc:214-437).  Here the same integer state machine runs on the host
 // over (argmax, max) pairs that the GPU produced in speculative batches:
 //   * up-path windows lie on a stride-N lattice until the next SFD lock, so a miss at (pos, off)
-//     launches one strided batch from pos to as far as samples are available (geometric growth);
+//     launches one strided batch from pos to the end of the buffered samples; the batches of
+//     every (lattice phase, offset) seen so far are kept, so a lattice that comes back after a
+//     later packet (there are only 16 phases) costs no new launch;
 //   * entering S_SFD_SYNC launches one stride-N/16 batch that covers the at most 10 calls x 16
 //     overlapped windows the reference can evaluate before it bails out (:283-292).
 // Every decision (tolerances, counters, integer divisions, squelch compare) is the reference's.
@@ -69,8 +71,8 @@ struct lora_demod_core {
   std::vector<lora_c32> buf;
   uint64_t base = 0, pos = 0;
   // GPU result caches
-  Run up_run, sfd_run;
-  size_t next_spec = 64;
+  std::vector<Run> up_runs;
+  Run sfd_run;
   bool staged = false;
   // instrumentation
   lora_core_trace *trace = nullptr; size_t max_trace = 0;
@@ -80,7 +82,7 @@ struct lora_demod_core {
 
 namespace {
 
-constexpr size_t kMinSpec = 64, kMaxSpec = 1u << 16;
+constexpr size_t kMaxSpec = 1u << 16, kMaxRuns = 48;
 
 int fail(lora_demod_core *c, int rc, const char *what) {
   c->err = std::string(what) + ": " + lora_hip_strerror(rc);
@@ -113,19 +115,23 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
 int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, float *val) {
   const unsigned n = c->d_num_symbols;
   size_t k;
-  if (!c->up_run.find(pos, off, n, &k)) {
-    // windows available from pos on this lattice; speculate geometrically
-    const uint64_t end = c->base + c->buf.size();
-    const size_t avail = (size_t)((end - pos - n) / n + 1);
-    const bool continues = !c->up_run.idx.empty() && c->up_run.stride == n && c->up_run.off0 == off &&
-                           pos == c->up_run.start + (uint64_t)c->up_run.idx.size() * n;
-    c->next_spec = continues ? (c->next_spec * 2 > kMaxSpec ? kMaxSpec : c->next_spec * 2) : kMinSpec;
-    const size_t count = avail < c->next_spec ? avail : c->next_spec;
-    int rc = launch_run(c, c->up_run, pos, n, count, off, 0, LORA_WIN_UP);
-    if (rc) return rc;
-    k = 0;
+  for (size_t r = c->up_runs.size(); r-- > 0;) {
+    if (c->up_runs[r].find(pos, off, n, &k)) { *idx = c->up_runs[r].idx[k]; *val = c->up_runs[r].val[k]; return LORA_HIP_OK; }
   }
-  *idx = c->up_run.idx[k]; *val = c->up_run.val[k];
+  // miss: drop batches that lie entirely behind the read index, then sweep this lattice to the
+  // end of the buffered samples
+  for (size_t r = 0; r < c->up_runs.size();) {
+    const Run &u = c->up_runs[r];
+    if (u.start + (uint64_t)u.idx.size() * u.stride <= c->pos) c->up_runs.erase(c->up_runs.begin() + r);
+    else r++;
+  }
+  if (c->up_runs.size() >= kMaxRuns) c->up_runs.erase(c->up_runs.begin());
+  const uint64_t end = c->base + c->buf.size();
+  const size_t avail = (size_t)((end - pos - n) / n + 1);
+  c->up_runs.emplace_back();
+  int rc = launch_run(c, c->up_runs.back(), pos, n, avail < kMaxSpec ? avail : kMaxSpec, off, 0, LORA_WIN_UP);
+  if (rc) { c->up_runs.pop_back(); return rc; }
+  *idx = c->up_runs.back().idx[0]; *val = c->up_runs.back().val[0];
   return LORA_HIP_OK;
 }
 

@@ -23,7 +23,9 @@ struct lora_hip_demod {
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
   void *d_desc = nullptr; size_t cap_desc = 0;
-  unsigned short *d_idx = nullptr; float *d_val = nullptr; size_t cap_out = 0;
+  // results for host callers: one device block [n_win floats | n_win u16] and its pinned mirror, so that
+  // a call costs one device-to-host copy
+  unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
   unsigned long long *d_dbg = nullptr;   // LORA_STAMPS builds only
   char hip_err[256] = {0};
   const char *kernel_name = "";
@@ -270,7 +272,8 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
   (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_idx); (void)hipFree(h->d_val);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out);
+  if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }
 
@@ -337,20 +340,30 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   if (out_dev) { p.out_idx = max_idx; p.out_val = max_val; }
   else {
     if (n_win > h->cap_out) {
-      size_t c1 = h->cap_out, c2 = h->cap_out;
-      if ((rc = grow(h, &h->d_idx, &c1, n_win)) != LORA_HIP_OK) return rc;
-      if ((rc = grow(h, &h->d_val, &c2, n_win)) != LORA_HIP_OK) return rc;
-      h->cap_out = c1 < c2 ? c1 : c2;
+      const size_t ncap = n_win + n_win / 4 + 64;
+      if (h->d_out) { (void)hipFree(h->d_out); h->d_out = nullptr; }
+      if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
+      h->cap_out = 0;
+      hipError_t e = hipMalloc((void **)&h->d_out, ncap * 6);
+      if (e != hipSuccess) { h->d_out = nullptr; hip_fail(h, e, "hipMalloc"); return LORA_HIP_ENOMEM; }
+      e = hipHostMalloc((void **)&h->h_out, ncap * 6, hipHostMallocDefault);
+      if (e != hipSuccess) { h->h_out = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+      h->cap_out = ncap;
     }
-    p.out_idx = h->d_idx; p.out_val = h->d_val;
+    p.out_val = reinterpret_cast<float *>(h->d_out);
+    p.out_idx = reinterpret_cast<unsigned short *>(h->d_out + n_win * 4);     // packed behind this call's values
   }
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win; p.twc = h->d_tw;
   for (int ps = 0; ps < 3; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
   if ((rc = launch(h, p)) != LORA_HIP_OK) return rc;
   if (!out_dev) {
-    HIP_TRY(h, hipMemcpyAsync(max_idx, h->d_idx, n_win * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(max_val, h->d_val, n_win * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    const size_t idx_off = n_win * 4;
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, n_win * 6, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(max_val, h->h_out, n_win * 4);
+    memcpy(max_idx, h->h_out + idx_off, n_win * 2);
+    return LORA_HIP_OK;
   }
   if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(h->stream));
   return LORA_HIP_OK;

@@ -1,0 +1,49 @@
+"""End-to-end and SFD-sweep measurements that are reported beside (never as) the headline value."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import gr_lora_amd as g
+from importlib import import_module
+synth = import_module("gr-lora_amd.synth")
+
+def sfd_sweep(sf, f, total_bytes=256 << 20, reps=5):
+    n = 1 << sf
+    ns = total_bytes // 8
+    dev = torch.device("cuda:0")
+    iq = torch.randn(ns, 2, device=dev, dtype=torch.float32)
+    count = (ns - n) // (n // 16) + 1
+    oi = torch.empty(count, dtype=torch.int16, device=dev); ov = torch.empty(count, dtype=torch.float32, device=dev)
+    h = g.HipDemod(sf, f)
+    s = torch.cuda.Stream(); h.set_stream(s.cuda_stream)
+    with torch.cuda.stream(s):
+        h.batch_strided(iq, 0, n // 16, count, 0, n // 16, g.capi.WIN_SFD, out_idx=oi, out_val=ov, async_=True); s.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            h.batch_strided(iq, 0, n // 16, count, 0, n // 16, g.capi.WIN_SFD, out_idx=oi, out_val=ov, async_=True)
+        e1.record(s); s.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"SFD sweep SF{sf} F{f}: {count} overlapped windows (stride N/16) {ms:.3f} ms -> {count/ms/1e3:.1f} Mwin/s "
+          f"= {count/16/ms/1e3:.2f} M symbol-times/s", flush=True)
+    h.close()
+
+def e2e(sf, f, seconds_of_capture=40):
+    cap = synth.capture(sf, int(125e3 * seconds_of_capture), symbols_per_packet=64, seed=3)
+    blk = g.demod(sf, False, 25.0, f)
+    blk.work(cap[: 64 << sf])            # warm up
+    blk.close()
+    blk = g.demod(sf, False, 25.0, f)
+    t0 = time.perf_counter()
+    pdus = blk.work(cap)
+    dt = time.perf_counter() - t0
+    st = blk.stats
+    print(f"end-to-end demod.work SF{sf} F{f}: {len(cap)} samples from host memory, {len(pdus)} PDUs, {st['calls']} calls, "
+          f"{st['windows']} GPU windows in {st['launches']} launches, {dt*1e3:.1f} ms -> {st['calls']/dt/1e6:.3f} Msym/s "
+          f"({len(cap)*8/dt/1e9:.2f} GB/s of IQ incl. PCIe)", flush=True)
+    blk.close()
+
+if __name__ == "__main__":
+    for sf, f in ((12, 2), (10, 2), (8, 2)):
+        sfd_sweep(sf, f)
+    for sf, f in ((12, 2), (9, 2), (8, 2)):
+        e2e(sf, f)
