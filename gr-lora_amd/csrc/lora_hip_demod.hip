@@ -18,7 +18,7 @@ struct lora_hip_demod {
   hipStream_t own_stream = nullptr, stream = nullptr;
   float2 *d_up = nullptr, *d_down = nullptr;
   float *d_win = nullptr;
-  float2 *d_tw = nullptr;       // twc then the pass tables
+  float2 *d_tw = nullptr;       // the pass tables
   size_t tw_off[3] = {0, 0, 0};
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
@@ -52,6 +52,9 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
   return LORA_HIP_OK;
 }
 
+#ifndef LORA_NO_CONST
+#define LORA_NO_CONST 0   // developer knob: 1 = never use the register-resident-taps variant
+#endif
 typedef void (*kernel_fn)(const KParams);
 struct Variant { kernel_fn fn, fn_const; size_t lds; int wpb; const char *name; };
 
@@ -91,7 +94,7 @@ int launch(lora_hip_demod *h, KParams &p) {
   p.dbg = h->d_dbg;
 #endif
   // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
-  const bool const_off = (p.desc == nullptr && p.off_step == 0);
+  const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
   hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
 #if LORA_STAMPS
   {
@@ -101,8 +104,8 @@ int launch(lora_hip_demod *h, KParams &p) {
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
     const double nw = (double)blocks * (lora_hip::kBlock / 64);
-    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f\n",
-            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw);
+    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f | L2 twiddles %.0f\n",
+            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw, sum[7] / nw);
   }
 #endif
   hipError_t e = hipGetLastError();
@@ -203,17 +206,15 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     memcpy(win.data(), window_n, n * sizeof(float));
   }
   // Twiddle tables, evaluated in double and rounded once (layouts: lora_hip_kernels.hip.h):
-  //   twc[rr][m]            = W_M^(rr*m*N/R)                       pass-0 input constants
+  //   (the pass-0 input constants W_M^(rr*m*N/R) are compile-time constants of the kernel)
   //   twp[ps][rr][m-1][jm]  = W_M^(m*(N/L_ps)*(F*jm + rr))         merged pass twiddles, ps >= 1
   std::vector<lora_c32> tw;
   auto wm = [&](unsigned long long e) {
     const double a = -2.0 * M_PI * (double)(e % m) / (double)m;
     return lora_c32{(float)std::cos(a), (float)std::sin(a)};
   };
-  const int R = lora_hip::plan_points((int)sf), NP = lora_hip::plan_passes((int)sf);
+  const int NP = lora_hip::plan_passes((int)sf);
   const unsigned F = fft_factor;
-  for (unsigned rr = 0; rr < F; rr++)
-    for (int k = 0; k < R; k++) tw.push_back(wm((unsigned long long)rr * k * (n / R)));
   {
     unsigned long long NS = lora_hip::plan_radix((int)sf, 0);
     for (int ps = 1; ps < NP; ps++) {
@@ -353,7 +354,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
     p.out_val = reinterpret_cast<float *>(h->d_out);
     p.out_idx = reinterpret_cast<unsigned short *>(h->d_out + n_win * 4);     // packed behind this call's values
   }
-  p.up = h->d_up; p.down = h->d_down; p.win = h->d_win; p.twc = h->d_tw;
+  p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 3; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
   if ((rc = launch(h, p)) != LORA_HIP_OK) return rc;

@@ -26,7 +26,6 @@ struct KParams {
   unsigned long long n_samples;
   const float2 *up, *down;      // 2N-entry chirp tables (demod_impl.cc:92-101)
   const float *win;             // N Kaiser taps (demod_impl.cc:85)
-  const float2 *twc;            // [F][R]   pass-0 input constants W_(F*R)^(rr*m)           (uniform)
   const void *twp[3];           // per pass ps>=1: merged twiddles, layout chosen by pass_table_in_lds()
   const void *desc;             // lora_win_desc[n_win] or nullptr for the strided form
   unsigned long long pos0, stride;
@@ -55,6 +54,32 @@ __device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.
 __device__ __forceinline__ float2 cmul_volk(float2 a, float2 b) {
   return make_float2(__fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)),
                      __fadd_rn(__fmul_rn(a.x, b.y), __fmul_rn(a.y, b.x)));
+}
+
+// 64th roots of unity, W_64^k = exp(-2 pi i k / 64), as compile-time constants: the pass-0 input
+// constants of the zero-padding twist, W_(F*R)^(rr*m), are all among them (F*R <= 64), so they
+// cost no load at all.  Values are cos(2 pi k / 64) evaluated in double and rounded once.
+constexpr float kCosQ64[17] = {
+    1.0f, 0.99518472f, 0.980785251f, 0.956940353f, 0.923879504f, 0.881921291f, 0.831469595f, 0.773010433f,
+    0.707106769f, 0.634393275f, 0.555570245f, 0.471396744f, 0.382683426f, 0.290284663f, 0.195090324f,
+    0.0980171412f, 0.0f};
+__device__ __forceinline__ constexpr float cos64(int k) {
+  k &= 63;
+  return k <= 16 ? kCosQ64[k] : k <= 32 ? -kCosQ64[32 - k] : k <= 48 ? -kCosQ64[k - 32] : kCosQ64[64 - k];
+}
+// a * W_64^k; k is a compile-time constant after unrolling, so the table lookups fold to literals
+__device__ __forceinline__ float2 mul_w64(float2 a, int k) {
+  k &= 63;
+  if (k == 0) return a;
+  if (k == 16) return make_float2(a.y, -a.x);     // -j
+  if (k == 32) return make_float2(-a.x, -a.y);
+  if (k == 48) return make_float2(-a.y, a.x);     // +j
+  const float c = cos64(k), sn = -cos64(k - 16);  // W = c + j*sn, sn = -sin(2 pi k / 64)
+  return make_float2(__builtin_fmaf(a.x, c, -(a.y * sn)), __builtin_fmaf(a.x, sn, a.y * c));
+}
+__device__ __forceinline__ float2 csqr(float2 a) {
+  const float ab = a.x * a.y;
+  return make_float2(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), ab + ab);
 }
 
 // ---- register-resident forward DFTs, natural order in and out ---------------------------
@@ -152,8 +177,12 @@ constexpr int kBlock = 256;
 #define LORA_STAMPS 0
 #endif
 #if LORA_STAMPS
+#define LORA_STAMP_PARAMS , unsigned long long (&stamp_acc)[8], unsigned long long &stamp_last
+#define LORA_STAMP_ARGS , stamp_acc, stamp_last
 #define LORA_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
 #else
+#define LORA_STAMP_PARAMS
+#define LORA_STAMP_ARGS
 #define LORA_STAMP(i) do { } while (0)
 #endif
 #ifndef LORA_SF12_DIGITS
@@ -212,11 +241,7 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 // What remains after the last pass is one factor per thread of magnitude 1, which |X|^2 drops.
 template <int LOGN, int F, int PS, int NS>
 __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const float2 *lds_tw,
-                                         const int tw, const KParams &p, const int rr
-#if LORA_STAMPS
-                                         , unsigned long long (&stamp_acc)[8], unsigned long long &stamp_last
-#endif
-                                         ) {
+                                         const int tw, const KParams &p, const int rr LORA_STAMP_PARAMS) {
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R;
   constexpr int NP = plan_passes(LOGN), r = plan_radix(LOGN, PS), nb = R / r;
   constexpr bool last = (PS == NP - 1);
@@ -279,11 +304,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
       for (int m = 0; m < r; m++) v[q + m * nb] = a[m];
     }
   }
-#if LORA_STAMPS
-  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr, stamp_acc, stamp_last);
-#else
-  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr);
-#endif
+  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr LORA_STAMP_ARGS);
 }
 
 template <int LOGN, int F>
@@ -302,29 +323,35 @@ constexpr int demod_lds_table_entries() { return pass_lds_offset(LOGN, F, plan_p
 // stride-17 transpose of exchange 2.
 template <int F>
 __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const float2 *lds_tw, const int tw,
-                                         const KParams &p, const int rr) {
+                                         const float2 w1, const int rr LORA_STAMP_PARAMS) {
   static_assert(pass_table_in_lds(12, F, 1) && !pass_table_in_lds(12, F, 2), "table placement assumed below");
   constexpr int ROW = 272;
   const int hi = tw >> 4, lo = tw & 15;
   Dft<16>::run(v);                                   // n2 -> ka
+  LORA_STAMP(2);
   __syncthreads();                                   // every wave is done with the previous transform's rows
+  LORA_STAMP(5);
   {
     float2 *o = tile + tw;
 #pragma unroll
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
+  LORA_STAMP(6);
   __syncthreads();
+  LORA_STAMP(5);
   {
     const float2 *i = tile + hi * ROW + lo;
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = i[m * 16];   // thread (ka = hi, n0 = lo), register n1 = m
   }
+  LORA_STAMP(6);
   {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
     for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tp[(m - 1) * 16]);
   }
   Dft<16>::run(v);                                   // n1 -> kb
+  LORA_STAMP(2);
   {
     float2 *o = tile + hi * ROW + lo;
 #pragma unroll
@@ -333,14 +360,15 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = i[m];        // thread (ka = hi, kb = lo), register n0 = m
   }
+  LORA_STAMP(6);
   {
-    // powers 1,2,4,8 of this butterfly's base twiddle W_M^(F*g + rr), g = ka + 16*kb
-    const int g = hi + 16 * lo;
-    const float4 *__restrict__ tp = reinterpret_cast<const float4 *>(p.twp[2]) + (rr * 2) * 256 + g;
-    const float4 t0 = tp[0], t1 = tp[256];
+    // powers of this butterfly's base twiddle w1 = W_M^(F*g + rr), g = ka + 16*kb: w1 is a per-thread
+    // constant of the whole launch (kept in registers by the caller), everything else is products,
+    // so that the loop holds no vector load besides the IQ prefetch
     float2 w[16];
-    w[1] = make_float2(t0.x, t0.y); w[2] = make_float2(t0.z, t0.w);
-    w[4] = make_float2(t1.x, t1.y); w[8] = make_float2(t1.z, t1.w);
+    w[1] = w1;
+    asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));     // loop-invariant, but 30 registers of hoisted powers would spill
+    w[2] = csqr(w[1]); w[4] = csqr(w[2]); w[8] = csqr(w[4]);
     w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
 #pragma unroll
     for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
@@ -472,6 +500,16 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       cwin[k] = (p.kind == 0) ? wk : 1.0f;
     }
   }
+  // SF12 digit mapping: base twiddle of this thread's last-pass butterfly, one per sub-transform
+  float2 w1c[(LOGN == 12 && LORA_SF12_DIGITS) ? F : 1];
+  if constexpr (LOGN == 12 && LORA_SF12_DIGITS) {
+    const int g = (tw >> 4) + 16 * (tw & 15);
+#pragma unroll
+    for (int rr = 0; rr < F; rr++) {
+      const float4 t = reinterpret_cast<const float4 *>(p.twp[2])[(rr * 2) * 256 + g];
+      w1c[rr] = make_float2(t.x, t.y);
+    }
+  }
   float2 nx[R];                    // raw IQ of the window about to be processed: sample tw + k*T
   {
     const float2 *__restrict__ src = p.iq + cur.pos + tw;
@@ -526,10 +564,9 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #pragma unroll
         for (int k = 0; k < R; k++) v[k] = x[k];
       } else {
-        const float2 *__restrict__ tc = p.twc + rr * R;     // wave-uniform -> scalar loads
-        v[0] = x[0];
+        static_assert(64 % (F * R) == 0, "pass-0 twist constants are 64th roots of unity");
 #pragma unroll
-        for (int k = 1; k < R; k++) v[k] = cmul(x[k], tc[k]);
+        for (int k = 0; k < R; k++) v[k] = mul_w64(x[k], rr * k * (64 / (F * R)));   // W_M^(rr*k*T)
       }
       if (rr == F - 1) {
         // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
@@ -544,12 +581,8 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
         }
       }
-#if LORA_STAMPS
-      fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr, stamp_acc, stamp_last);
-#else
-      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, p, rr);
-      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr);
-#endif
+      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, w1c[rr], rr LORA_STAMP_ARGS);
+      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
       if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
       LORA_STAMP(4);
@@ -561,7 +594,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
         const float mag = magsq(v[k]);
         if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);      // thread 0 holds bin 0 in both mappings
         // bin held by register k: generic Stockham tw + k*T; SF12 digit mapping (tw>>4) + 16*(tw&15) + 256*k
-        const int kout = (LOGN == 12 && LORA_SF12_DIGITS && !LORA_STAMPS) ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
+        const int kout = (LOGN == 12 && LORA_SF12_DIGITS) ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
         if (mag > b.v) { b.v = mag; b.i = F * kout + rr; }
       }
       best = (rr == 0) ? b : better(best, b);
