@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip_de
 
 OK, EINVAL, EUNSUPPORTED, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4, -5
 WIN_UP, WIN_SFD = 0, 1
-IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC = 1, 2, 4, 8
+IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED = 1, 2, 4, 8, 16
 
 WIN_DESC_DTYPE = np.dtype([("pos", "<u8"), ("chirp_off", "<u2"), ("kind", "u1"), ("reserved", "u1", (5,))])
 assert WIN_DESC_DTYPE.itemsize == 16
@@ -28,7 +28,7 @@ EXPORTS = (
     # include/lora_demod_core.h
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
-    "lora_demod_core_last_error",
+    "lora_demod_core_last_error", "lora_demod_core_preload",
 )
 
 PDU_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint16), C.c_size_t)
@@ -84,6 +84,7 @@ def lib():
         getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = u64
     L.lora_demod_core_state.argtypes = [vp]; L.lora_demod_core_state.restype = i
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
+    L.lora_demod_core_preload.argtypes = [vp, u64, sz, vp, vp]; L.lora_demod_core_preload.restype = i
     _lib = L
     return L
 
@@ -125,6 +126,7 @@ class HipDemod:
 
     def __init__(self, sf, fft_factor, beta=25.0, device=0, window=None, upchirp=None, downchirp=None):
         self.sf, self.fft_factor, self.N = sf, fft_factor, 1 << sf
+        self._staged_n = 0
         self._h = C.c_void_p()
         args = [None, None, None]
         if window is not None:
@@ -174,14 +176,25 @@ class HipDemod:
         self._check(lib().lora_hip_demod_batch(self._h, pi, n_samples, pd, n_win, po, pv, flags))
         return out_idx, out_val
 
+    def stage_iq(self, iq):
+        """lora_hip_demod_stage_iq: copy a host capture into the handle's device buffer once; later
+        calls pass iq=None and read it there."""
+        x = np.ascontiguousarray(iq, np.complex64)
+        self._check(lib().lora_hip_demod_stage_iq(self._h, x.ctypes.data, len(x)))
+        self._staged_n = len(x)
+
     def batch_strided(self, iq, pos0, stride, count, chirp_off=0, chirp_off_step=0, kind=WIN_UP,
                       out_idx=None, out_val=None, async_=False):
         out_idx, out_val = self._outputs(count, out_idx, out_val)
         pi, di = _ptr(iq); po, do = _ptr(out_idx); pv, dv = _ptr(out_val)
         assert do == dv
         flags = (IQ_ON_DEVICE if di else 0) | (OUT_ON_DEVICE if do else 0) | (ASYNC if async_ else 0)
-        n_samples = iq.numel() if _is_torch(iq) else len(iq)
-        if _is_torch(iq) and iq.dtype.is_floating_point and not iq.dtype.is_complex:
+        if iq is None:                        # the capture staged by stage_iq()
+            flags |= IQ_STAGED
+            n_samples = self._staged_n
+        else:
+            n_samples = iq.numel() if _is_torch(iq) else len(iq)
+        if iq is not None and _is_torch(iq) and iq.dtype.is_floating_point and not iq.dtype.is_complex:
             n_samples //= 2
         self._check(lib().lora_hip_demod_batch_strided(self._h, pi, n_samples, pos0, stride, count, chirp_off,
                                                        chirp_off_step, kind, po, pv, flags))

@@ -71,7 +71,8 @@ struct lora_demod_core {
   std::vector<lora_c32> buf;
   uint64_t base = 0, pos = 0;
   // GPU result caches
-  std::vector<Run> up_runs;
+  std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
+  std::vector<Run> pre_runs;     // handed in through lora_demod_core_preload
   Run sfd_run;
   bool staged = false;
   // instrumentation
@@ -118,18 +119,28 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
   for (size_t r = c->up_runs.size(); r-- > 0;) {
     if (c->up_runs[r].find(pos, off, n, &k)) { *idx = c->up_runs[r].idx[k]; *val = c->up_runs[r].val[k]; return LORA_HIP_OK; }
   }
-  // miss: drop batches that lie entirely behind the read index, then sweep this lattice to the
-  // end of the buffered samples
+  for (size_t r = c->pre_runs.size(); r-- > 0;) {
+    if (c->pre_runs[r].find(pos, off, n, &k)) { *idx = c->pre_runs[r].idx[k]; *val = c->pre_runs[r].val[k]; return LORA_HIP_OK; }
+  }
+  // miss: drop batches that lie entirely behind the read index
+  auto behind = [&](const Run &u) { return u.start + (uint64_t)u.idx.size() * u.stride <= c->pos; };
   for (size_t r = 0; r < c->up_runs.size();) {
-    const Run &u = c->up_runs[r];
-    if (u.start + (uint64_t)u.idx.size() * u.stride <= c->pos) c->up_runs.erase(c->up_runs.begin() + r);
+    if (behind(c->up_runs[r])) c->up_runs.erase(c->up_runs.begin() + r);
+    else r++;
+  }
+  for (size_t r = 0; r < c->pre_runs.size();) {
+    if (behind(c->pre_runs[r])) c->pre_runs.erase(c->pre_runs.begin() + r);
     else r++;
   }
   if (c->up_runs.size() >= kMaxRuns) c->up_runs.erase(c->up_runs.begin());
+  // Sweep this (lattice phase, offset) to the end of the buffered samples: a window costs the GPU
+  // nanoseconds, a launch and its synchronisation tens of microseconds, and the same lattice tends to
+  // come back after later packets (there are only 16 phases).
   const uint64_t end = c->base + c->buf.size();
   const size_t avail = (size_t)((end - pos - n) / n + 1);
+  const size_t want = kMaxSpec;
   c->up_runs.emplace_back();
-  int rc = launch_run(c, c->up_runs.back(), pos, n, avail < kMaxSpec ? avail : kMaxSpec, off, 0, LORA_WIN_UP);
+  int rc = launch_run(c, c->up_runs.back(), pos, n, avail < want ? avail : want, off, 0, LORA_WIN_UP);
   if (rc) { c->up_runs.pop_back(); return rc; }
   *idx = c->up_runs.back().idx[0]; *val = c->up_runs.back().val[0];
   return LORA_HIP_OK;
@@ -302,6 +313,19 @@ int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, 
     c->base += drop;
     c->staged = false;
   }
+  return LORA_HIP_OK;
+}
+
+int lora_demod_core_preload(lora_demod_core_t *c, uint64_t start, size_t count, const uint16_t *idx, const float *val) {
+  if (!c || (count && (!idx || !val))) return LORA_HIP_EINVAL;
+  if (count == 0) return LORA_HIP_OK;
+  if (start % (c->d_num_symbols / OVERLAP_FACTOR)) return LORA_HIP_EINVAL;      // read indices stay on the N/16 lattice
+  try {
+    c->pre_runs.emplace_back();
+    Run &r = c->pre_runs.back();
+    r.start = start; r.stride = c->d_num_symbols; r.off0 = 0; r.off_step = 0; r.kind = LORA_WIN_UP;
+    r.idx.assign(idx, idx + count); r.val.assign(val, val + count);
+  } catch (const std::bad_alloc &) { return LORA_HIP_ENOMEM; }
   return LORA_HIP_OK;
 }
 

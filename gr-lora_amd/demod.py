@@ -76,6 +76,15 @@ class demod:
         n = min(int(capi.lib().lora_demod_core_calls(self._h)), len(self._trace))
         return self._trace[:n]
 
+    def preload(self, start, idx, val):
+        """lora_demod_core_preload: up-path results (offset 0) of the windows starting at framed-stream
+        index start + k*N, produced ahead of time (shard.sharded_detect_sweep)."""
+        idx = np.ascontiguousarray(idx, np.uint16); val = np.ascontiguousarray(val, np.float32)
+        assert len(idx) == len(val)
+        rc = capi.lib().lora_demod_core_preload(self._h, int(start), len(idx), idx.ctypes.data, val.ctypes.data)
+        if rc:
+            raise capi.LoraHipError(rc)
+
     def work(self, samples):
         """Feed complex64 samples; returns the PDUs completed by this call as u16 arrays."""
         x = np.ascontiguousarray(samples, np.complex64)

@@ -57,6 +57,21 @@ LORA_HIP_API void lora_demod_core_destroy(lora_demod_core_t *c);
 LORA_HIP_API int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in,
                                       lora_pdu_cb cb, void *user);
 
+/* Time-segment sharding of one long capture (design A; no counterpart in the
+ * reference, which is one sequential thread per channel).  Outside READ_HEADER / READ_PAYLOAD the
+ * up-path result of a call (lib/demod_impl.cc:177-206 with downchirp offset 0) depends only on its
+ * read index, and read indices stay on the N/16 lattice (num_consumed is N or ol*N/16 + 5N/4, :344).
+ * Those results can therefore be produced ahead of time, by any GPU, with
+ * lora_hip_demod_batch_strided(pos0, stride = N, chirp_off = 0, kind = LORA_WIN_UP) for each of the
+ * 16 lattice phases, and handed over here before the samples are fed: work() then replays the
+ * reference's state machine over them, so the window grid is the sequential run's by construction,
+ * and launches only the SFD sweeps and header/payload windows itself.
+ * idx[k], val[k] = result of the window starting at framed-stream index start + k*N (the framed
+ * stream is 3N-1 zeros followed by the samples, as in lora_core_trace.pos); start must be a multiple
+ * of N/16.  The arrays are copied.  Results that never match a call are simply not used. */
+LORA_HIP_API int lora_demod_core_preload(lora_demod_core_t *c, uint64_t start, size_t count,
+                                         const uint16_t *idx, const float *val);
+
 /* Optional per-call trace: rows are appended to `rows` (caller-owned) up to max_rows; the number
  * of calls so far (may exceed max_rows) is returned by lora_demod_core_calls(). */
 LORA_HIP_API int lora_demod_core_set_trace(lora_demod_core_t *c, lora_core_trace *rows, size_t max_rows);
