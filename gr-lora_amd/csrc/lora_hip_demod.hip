@@ -208,6 +208,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   // Twiddle tables, evaluated in double and rounded once (layouts: lora_hip_kernels.hip.h):
   //   (the pass-0 input constants W_M^(rr*m*N/R) are compile-time constants of the kernel)
   //   twp[ps][rr][m-1][jm]  = W_M^(m*(N/L_ps)*(F*jm + rr))         merged pass twiddles, ps >= 1
+  //   (a last pass too big for LDS stores m = 1 only; the kernel keeps it in registers)
   std::vector<lora_c32> tw;
   auto wm = [&](unsigned long long e) {
     const double a = -2.0 * M_PI * (double)(e % m) / (double)m;
@@ -219,20 +220,14 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     unsigned long long NS = lora_hip::plan_radix((int)sf, 0);
     for (int ps = 1; ps < NP; ps++) {
       const unsigned long long r = lora_hip::plan_radix((int)sf, ps), L = NS * r;
-      if (tw.size() % 2) tw.push_back(lora_c32{0.f, 0.f});          // keep float4 tables 16-byte aligned
       h->tw_off[ps] = tw.size();
       const bool small = lora_hip::pass_table_in_lds((int)sf, (int)F, ps);
       for (unsigned rr = 0; rr < F; rr++) {
         if (small) {          // float2 [F][r-1][NS]
           for (unsigned long long mm = 1; mm < r; mm++)
             for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(mm * (n / L) * (F * jm + rr)));
-        } else {              // float4 [F][2][NS] = { W^1, W^2 } then { W^4, W^8 } of the base twiddle
-          for (unsigned long long h2 = 0; h2 < 2; h2++)
-            for (unsigned long long jm = 0; jm < NS; jm++) {
-              const unsigned long long base_e = (n / L) * (F * jm + rr);
-              tw.push_back(wm((h2 ? 4 : 1) * base_e));
-              tw.push_back(wm((h2 ? 8 : 2) * base_e));
-            }
+        } else {              // float2 [F][NS]: the base twiddle of each butterfly only
+          for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm((n / L) * (F * jm + rr)));
         }
       }
       NS = L;

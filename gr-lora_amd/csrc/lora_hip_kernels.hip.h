@@ -26,7 +26,7 @@ struct KParams {
   unsigned long long n_samples;
   const float2 *up, *down;      // 2N-entry chirp tables (demod_impl.cc:92-101)
   const float *win;             // N Kaiser taps (demod_impl.cc:85)
-  const void *twp[3];           // per pass ps>=1: merged twiddles, layout chosen by pass_table_in_lds()
+  const void *twp[3];           // per pass ps>=1: merged twiddles: float2 [F][r-1][NS] (LDS) or [F][NS] (base only)
   const void *desc;             // lora_win_desc[n_win] or nullptr for the strided form
   unsigned long long pos0, stride;
   unsigned off0, off_step, kind;
@@ -196,8 +196,9 @@ constexpr int kBlock = 256;
 // return to the registers at only ~32 B/clk per CU (measured: TD busy 84 % with tables in L2), so
 // per-window table traffic is kept off that path:
 //   small tables live in LDS as float2 [F][r-1][NS]      (copied once per workgroup)
-//   big tables (SF12, SF11/SF10 at high F) stay in L2 as float4 [F][2][NS] holding only the
-//   powers W^1,W^2 | W^4,W^8 of each butterfly's base twiddle; the other powers are products.
+//   big tables (last pass of SF12, SF11 at F >= 2, SF10 at F = 4) are not tables at all in the loop: a
+//   thread's butterflies are the same for every window, so the base twiddle W^1 of each is read once
+//   per launch from a float2 [F][NS] table and kept in registers; the other powers are products.
 constexpr int kLdsTableBytes = 16384;
 constexpr int pass_entries(int logn, int f, int ps) { return f * (plan_radix(logn, ps) - 1) * plan_ns(logn, ps); }
 constexpr int lds_table_bytes_before(int logn, int f, int ps);
@@ -241,7 +242,7 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 // What remains after the last pass is one factor per thread of magnitude 1, which |X|^2 drops.
 template <int LOGN, int F, int PS, int NS>
 __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const float2 *lds_tw,
-                                         const int tw, const KParams &p, const int rr LORA_STAMP_PARAMS) {
+                                         const int tw, const float2 *wb, const int rr LORA_STAMP_PARAMS) {
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R;
   constexpr int NP = plan_passes(LOGN), r = plan_radix(LOGN, PS), nb = R / r;
   constexpr bool last = (PS == NP - 1);
@@ -277,15 +278,16 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
 #pragma unroll
         for (int m = 1; m < r; m++) a[m] = cmul(a[m], tp[(m - 1) * NS]);
       } else {
-        // powers 1,2,4,8 of this butterfly's base twiddle from L2; the rest are products
-        static_assert(r == 8 || r == 16, "power table covers radix 8 and 16");
-        const float4 *__restrict__ tp = reinterpret_cast<const float4 *>(p.twp[PS]) + (rr * 2) * NS + jm;
-        const float4 t0 = tp[0], t1 = tp[NS];
+        // base twiddle of this butterfly from the caller's registers; every other power is a product
+        static_assert(r == 8 || r == 16, "power chain covers radix 8 and 16");
+        static_assert(last, "only the last pass has a table too big for LDS");
         float2 w[16];
-        w[1] = make_float2(t0.x, t0.y); w[2] = make_float2(t0.z, t0.w);
-        w[4] = make_float2(t1.x, t1.y); w[8] = make_float2(t1.z, t1.w);
+        w[1] = wb[q];
+        asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));   // loop-invariant, but hoisted powers would cost 2r registers
+        w[2] = csqr(w[1]); w[4] = csqr(w[2]);
         w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
         if constexpr (r == 16) {
+          w[8] = csqr(w[4]);
 #pragma unroll
           for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
         }
@@ -304,7 +306,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
       for (int m = 0; m < r; m++) v[q + m * nb] = a[m];
     }
   }
-  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, p, rr LORA_STAMP_ARGS);
+  if constexpr (!last) fft_pass<LOGN, F, PS + 1, NS * r>(v, tile, lds_tw, tw, wb, rr LORA_STAMP_ARGS);
 }
 
 template <int LOGN, int F>
@@ -500,14 +502,21 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       cwin[k] = (p.kind == 0) ? wk : 1.0f;
     }
   }
-  // SF12 digit mapping: base twiddle of this thread's last-pass butterfly, one per sub-transform
-  float2 w1c[(LOGN == 12 && LORA_SF12_DIGITS) ? F : 1];
-  if constexpr (LOGN == 12 && LORA_SF12_DIGITS) {
-    const int g = (tw >> 4) + 16 * (tw & 15);
+  // last pass with a table too big for LDS: the base twiddle W_M^((N/L)*(F*jm + rr)) of each of this
+  // thread's butterflies, per sub-transform, for the whole launch
+  constexpr int NPS = plan_passes(LOGN), NSL = plan_ns(LOGN, NPS - 1), NBL = R / plan_radix(LOGN, NPS - 1);
+  constexpr bool kBaseRegs = !pass_table_in_lds(LOGN, F, NPS - 1);
+  constexpr bool kDigits = (LOGN == 12 && LORA_SF12_DIGITS);
+  float2 wb[kBaseRegs ? F * NBL : 1];
+  if constexpr (kBaseRegs) {
+    const float2 *__restrict__ tab = reinterpret_cast<const float2 *>(p.twp[NPS - 1]);
 #pragma unroll
     for (int rr = 0; rr < F; rr++) {
-      const float4 t = reinterpret_cast<const float4 *>(p.twp[2])[(rr * 2) * 256 + g];
-      w1c[rr] = make_float2(t.x, t.y);
+#pragma unroll
+      for (int q = 0; q < NBL; q++) {
+        const int jm = kDigits ? ((tw >> 4) + 16 * (tw & 15)) : ((tw + q * T) & (NSL - 1));
+        wb[rr * NBL + q] = tab[rr * NSL + jm];
+      }
     }
   }
   float2 nx[R];                    // raw IQ of the window about to be processed: sample tw + k*T
@@ -581,8 +590,8 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
         }
       }
-      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, w1c[rr], rr LORA_STAMP_ARGS);
-      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, p, rr LORA_STAMP_ARGS);
+      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, wb[rr], rr LORA_STAMP_ARGS);
+      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? rr * NBL : 0), rr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
       if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
       LORA_STAMP(4);
