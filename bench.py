@@ -104,6 +104,23 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # what a plain device copy of the same buffer reaches on this GPU (read + write bytes per second):
+    # the practical ceiling beside the 8 TB/s specification; outside the timed region
+    copy_gbs = None
+    if rank == 0:
+        raw = iq.view(torch.float32)
+        dst = torch.empty_like(raw)
+        with torch.cuda.stream(stream):
+            dst.copy_(raw)
+            c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+            c0.record(stream)
+            for _ in range(5):
+                dst.copy_(raw)
+            c1.record(stream)
+        stream.synchronize()
+        copy_gbs = 2 * raw.numel() * 4 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del dst
+
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -136,7 +153,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "bytes_per_symbol": bytes_per_sym,
-                         "symbols_per_launch": count},
+                         "symbols_per_launch": count,
+                         "device_copy_gbs": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)},
         }
         if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cap)
