@@ -104,8 +104,8 @@ int launch(lora_hip_demod *h, KParams &p) {
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
     const double nw = (double)blocks * (lora_hip::kBlock / 64);
-    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f | L2 twiddles %.0f\n",
-            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw, sum[7] / nw);
+    fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f | s_memtime/s_memrealtime %.2f (x100 MHz)\n",
+            v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6]) / sum[7]);
   }
 #endif
   hipError_t e = hipGetLastError();

@@ -171,7 +171,7 @@ constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++
 
 constexpr int kBlock = 256;
 #ifndef LORA_ABL
-#define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads
+#define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax
 #endif
 #ifndef LORA_STAMPS
 #define LORA_STAMPS 0
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #if LORA_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference
 #endif
 
   // Reduction over the T threads of a window.  Part 1 (end of window i): wave64 shuffles, then one
@@ -455,12 +456,29 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
   // The two red[] halves alternate, so a half is rewritten two windows later, behind barriers.
   auto reduce_partial = [&](Best best, const int par) -> Best {
     constexpr int LANES = T < 64 ? T : 64;
-#pragma unroll
-    for (int s = LANES / 2; s >= 1; s >>= 1) {
-      Best o;
-      o.v = __shfl_xor(best.v, s, 64);
-      o.i = __shfl_xor(best.i, s, 64);
-      best = better(best, o);
+    // DPP cross-lane steps (VALU data path, a few cycles each) instead of ds_bpermute shuffles (~100
+    // cycles each, 12 of them in a dependent chain per window)
+#define LORA_DPP_STEP(ctrl, row_mask)                                                                         \
+    {                                                                                                         \
+      Best o;                                                                                                 \
+      o.v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, best.v),            \
+                                                                  __builtin_bit_cast(int, best.v), ctrl, row_mask, 0xF, false)); \
+      o.i = __builtin_amdgcn_update_dpp(best.i, best.i, ctrl, row_mask, 0xF, false);                          \
+      best = better(best, o);                                                                                 \
+    }
+    if (!(LORA_ABL & 8)) {
+      if (LANES >= 2) LORA_DPP_STEP(0xB1, 0xF)      // quad_perm [1,0,3,2]: lane ^ 1
+      if (LANES >= 4) LORA_DPP_STEP(0x4E, 0xF)      // quad_perm [2,3,0,1]: lane ^ 2
+      if (LANES >= 8) LORA_DPP_STEP(0x141, 0xF)     // row_half_mirror: every lane of 8 has the best of 8
+      if (LANES >= 16) LORA_DPP_STEP(0x140, 0xF)    // row_mirror: every lane of a row has the row's best
+      if (LANES >= 32) LORA_DPP_STEP(0x142, 0xA)    // row_bcast:15 into rows 1 and 3
+      if (LANES >= 64) LORA_DPP_STEP(0x143, 0xC)    // row_bcast:31 into rows 2 and 3: lane 63 has the wave's best
+    }
+#undef LORA_DPP_STEP
+    if (LANES == 64) {
+      // the wave's result sits in lane 63; make it uniform (two v_readlane)
+      best.v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best.v), 63));
+      best.i = __builtin_amdgcn_readlane(best.i, 63);
     }
     if (T > 64) {
       if ((tid & 63) == 0) red[par * (kBlock / 64) + tid / 64] = best;
@@ -604,7 +622,11 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
         if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);      // thread 0 holds bin 0 in both mappings
         // bin held by register k: generic Stockham tw + k*T; SF12 digit mapping (tw>>4) + 16*(tw&15) + 256*k
         const int kout = (LOGN == 12 && LORA_SF12_DIGITS) ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
+#if LORA_ABL & 16
+        b.v += mag;
+#else
         if (mag > b.v) { b.v = mag; b.i = F * kout + rr; }
+#endif
       }
       best = (rr == 0) ? b : better(best, b);
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
@@ -620,6 +642,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
     combine_store(prev, prev_best, prev_nan, par ^ 1);
   }
 #if LORA_STAMPS
+  stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
   if (p.dbg && (tid & 63) == 0) {
     for (int i = 0; i < 8; i++) p.dbg[(blockIdx.x * (kBlock / 64) + tid / 64) * 8 + i] = stamp_acc[i];
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/pmc.sh <tag> <sf> <F> : PMC passes for one kernel config; results under gpurun_out/pmc_<tag>/
 tag=$1; sf=$2; f=$3
-R=$PWD; export TMPDIR=/tmp; cd /tmp
+R=$PWD; export TMPDIR=/tmp; cd /tmp; mkdir -p $R/gpurun_out/pmc_$tag
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
