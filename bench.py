@@ -141,6 +141,17 @@ def main():
                 j = json.load(f)
             if j.get("kernel") == h.kernel_name and j.get("windows_per_launch") == count:
                 traffic = j.get("hbm_bytes_per_launch")
+        secondary = None
+        vc = os.path.join(ROOT, "profiles", "valu_count.json")
+        if os.path.exists(vc):
+            with open(vc) as f:
+                j = json.load(f)
+            if j.get("kernel") == h.kernel_name:
+                # the roof that actually binds at SF12 F=2 (SURVEY 8d asks for it beside the HBM one)
+                ach = j["valu_wave_instr_per_symbol"] * count / (kernel_ms * 1e-3) / 1e9
+                secondary = {"bound": "valu_f32", "achieved": round(ach, 1), "peak": j["peak_spec_g_wave_instr_per_s"],
+                             "unit": "G wave-instr/s", "frac": round(ach / j["peak_spec_g_wave_instr_per_s"], 4),
+                             "wave_instr_per_symbol": j["valu_wave_instr_per_symbol"]}
         line = {
             "metric": "demodulated symbols/sec (Msym/s) at SF12 fft_factor=2",
             "value": round(value, 3), "unit": "Msym/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -154,7 +165,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "bytes_per_symbol": bytes_per_sym,
                          "symbols_per_launch": count,
-                         "device_copy_gbs": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)},
+                         "device_copy_gbs": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
+                         "secondary": secondary},
         }
         if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cap)

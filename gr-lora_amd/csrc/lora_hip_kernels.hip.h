@@ -171,7 +171,7 @@ constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++
 
 constexpr int kBlock = 256;
 #ifndef LORA_ABL
-#define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax
+#define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax, 32 no LDS exchanges (SF12), 64 IQ from L2
 #endif
 #ifndef LORA_STAMPS
 #define LORA_STAMPS 0
@@ -330,6 +330,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   constexpr int ROW = 272;
   const int hi = tw >> 4, lo = tw & 15;
   Dft<16>::run(v);                                   // n2 -> ka
+#if !(LORA_ABL & 32)
   LORA_STAMP(2);
   __syncthreads();                                   // every wave is done with the previous transform's rows
   LORA_STAMP(5);
@@ -347,6 +348,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     for (int m = 0; m < 16; m++) v[m] = i[m * 16];   // thread (ka = hi, n0 = lo), register n1 = m
   }
   LORA_STAMP(6);
+#endif
   {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
@@ -354,6 +356,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   }
   Dft<16>::run(v);                                   // n1 -> kb
   LORA_STAMP(2);
+#if !(LORA_ABL & 32)
   {
     float2 *o = tile + hi * ROW + lo;
 #pragma unroll
@@ -363,6 +366,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     for (int m = 0; m < 16; m++) v[m] = i[m];        // thread (ka = hi, kb = lo), register n0 = m
   }
   LORA_STAMP(6);
+#endif
   {
     // powers of this butterfly's base twiddle w1 = W_M^(F*g + rr), g = ka + 16*kb: w1 is a per-thread
     // constant of the whole launch (kept in registers by the caller), everything else is products,
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       if (rr == F - 1) {
         // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
         asm volatile("" ::: "memory");
-        const float2 *__restrict__ src = p.iq + nxt.pos + tw;
+        const float2 *__restrict__ src = p.iq + ((LORA_ABL & 64) ? 0 : nxt.pos) + tw;   // ABL 64: every window reads window 0 (L2)
 #pragma unroll
         for (int k = 0; k < R; k++) {
 #if LORA_ABL & 1
