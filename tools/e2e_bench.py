@@ -27,6 +27,28 @@ def sfd_sweep(sf, f, total_bytes=256 << 20, reps=5):
           f"= {count/16/ms/1e3:.2f} M symbol-times/s", flush=True)
     h.close()
 
+def single_capture_latency(sf=12, f=2, n_samples=1_250_000, reps=50):
+    """BASELINE cfg 2 as one call: a 10 s capture resident in HBM, every stride-N window, host sees the results."""
+    n = 1 << sf
+    cap = synth.capture(sf, n_samples, symbols_per_packet=64, seed=2)
+    iq = torch.from_numpy(cap).cuda()
+    count = len(cap) // n
+    h = g.HipDemod(sf, f)
+    oi = torch.empty(count, dtype=torch.int16, device="cuda"); ov = torch.empty(count, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        h.batch_strided(iq, 0, n, count, out_idx=oi, out_val=ov)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h.batch_strided(iq, 0, n, count, out_idx=oi, out_val=ov)       # synchronous: returns when results are in HBM
+    dev = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h.batch_strided(iq, 0, n, count)                                  # results copied to host memory
+    host = (time.perf_counter() - t0) / reps
+    print(f"single capture SF{sf} F{f}: {count} windows of a {n_samples}-sample capture in HBM: {dev*1e6:.0f} us per call "
+          f"(results in HBM), {host*1e6:.0f} us with results in host memory", flush=True)
+    h.close()
+
 def e2e(sf, f, seconds_of_capture=40):
     cap = synth.capture(sf, int(125e3 * seconds_of_capture), symbols_per_packet=64, seed=3)
     blk = g.demod(sf, False, 25.0, f)
@@ -64,6 +86,7 @@ def e2e_design_a(sf, f, seconds_of_capture=40):
     blk.close(); sweep.close()
 
 if __name__ == "__main__":
+    single_capture_latency()
     for sf, f in ((12, 2), (10, 2), (8, 2)):
         sfd_sweep(sf, f)
     for sf, f in ((12, 2), (9, 2), (8, 2)):
