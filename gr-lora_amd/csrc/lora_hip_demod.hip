@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <algorithm>
 
 using lora_hip::KParams;
 
@@ -26,6 +27,7 @@ struct lora_hip_demod {
   // results for host callers: one device block [n_win floats | n_win u16] and its pinned mirror, so that
   // a call costs one device-to-host copy
   unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
+  unsigned *d_ticket = nullptr;          // window-group ticket counter of the persistent kernel
   unsigned long long *d_dbg = nullptr;   // LORA_STAMPS builds only
   char hip_err[256] = {0};
   const char *kernel_name = "";
@@ -93,6 +95,11 @@ int launch(lora_hip_demod *h, KParams &p) {
   (void)hipMemsetAsync(h->d_dbg, 0, ndbg * sizeof(unsigned long long), h->stream);
   p.dbg = h->d_dbg;
 #endif
+  {
+    hipError_t em = hipMemsetAsync(h->d_ticket, 0, lora_hip::kTicketQueues * lora_hip::kTicketStride * sizeof(unsigned), h->stream);
+    if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
+    p.ticket = h->d_ticket;
+  }
   // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
   const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
   hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
@@ -104,6 +111,14 @@ int launch(lora_hip_demod *h, KParams &p) {
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
     const double nw = (double)blocks * (lora_hip::kBlock / 64);
+    {   // spread of per-wave lifetimes (100 MHz ticks): static grid-stride shares, so equal work per wave
+      std::vector<double> life;
+      for (size_t w = 0; w < ndbg / 8; w++) life.push_back((double)hd[w * 8 + 7]);
+      std::sort(life.begin(), life.end());
+      fprintf(stderr, "[stamps] wave lifetime (us): min %.1f p10 %.1f p33 %.1f p50 %.1f p67 %.1f p90 %.1f max %.1f\n", life.front() / 100,
+              life[life.size() / 10] / 100, life[life.size() / 3] / 100, life[life.size() / 2] / 100, life[2 * life.size() / 3] / 100,
+              life[9 * life.size() / 10] / 100, life.back() / 100);
+    }
     fprintf(stderr, "[stamps] %s blocks=%u per-wave cycles: top %.0f | taps+dechirp %.0f | fft compute %.0f | barrier wait %.0f | lds gather %.0f | magsq %.0f | reduce+store %.0f | s_memtime/s_memrealtime %.2f (x100 MHz)\n",
             v.name, blocks, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[6] / nw, sum[3] / nw, sum[4] / nw, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6]) / sum[7]);
   }
@@ -243,6 +258,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_down, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_win, n * sizeof(float)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_ticket, lora_hip::kTicketQueues * lora_hip::kTicketStride * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
@@ -268,7 +284,7 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
   (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }

@@ -33,6 +33,7 @@ struct KParams {
   unsigned n_win;
   unsigned short *out_idx;
   float *out_val;
+  unsigned *ticket;             // kTicketQueues counters, 128 B apart, zeroed before the launch
   unsigned long long *dbg;      // diagnostic builds only (LORA_STAMPS): per-workgroup phase cycle sums
 };
 
@@ -170,6 +171,7 @@ constexpr int plan_radix(int logn, int ps) {
 constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++) v *= plan_radix(logn, i); return v; }
 
 constexpr int kBlock = 256;
+constexpr unsigned kTicketQueues = 8, kTicketStride = 32;   // 8 counters, 128 bytes apart
 #ifndef LORA_ABL
 #define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax, 32 no LDS exchanges (SF12), 64 IQ from L2
 #endif
@@ -414,8 +416,15 @@ __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned wi
   return c;
 }
 
-// Persistent workgroups: each walks the windows grid-stride (WPB windows per iteration), software
-// pipelined so that a wave never waits on HBM with nothing else to do:
+// Persistent workgroups take groups of WPB windows from a global ticket counter.  The shares must be
+// dynamic: a SIMD issues VALU work for its waves in pairs, so with three resident workgroups per CU
+// one of them runs up to twice as fast as the other two in VALU-bound phases (measured: equal static
+// shares finish 28 % apart; profiles/r01_dft_rate_microbench.txt).  The ticket of the group that is
+// two or three iterations ahead is drawn by thread 0 at the top of an iteration and published through a
+// small LDS ring at its end, so that every thread finds the next group behind barriers that exist anyway.  One counter for the whole chip would serialise at ~13 ns per atomic
+// (measured: 32768 groups = 0.42 ms), so there are 8 queues, chosen by blockIdx % 8 (workgroups that
+// share an XCD), each owning every 8th group: static shares between XCDs, dynamic ones inside.  Software pipelining, so that a wave never waits on HBM with nothing
+// else to do:
 //   * the raw IQ of window i+1 is loaded into registers while the last sub-transform of window i
 //     runs (its registers are those of x, dead by then);
 //   * CONST_OFF (strided sweep with one chirp offset: the steady-state path): the chirp and
@@ -509,8 +518,23 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
     }
   };
 
-  const unsigned step = gridDim.x * WPB;
-  WinCtx cur = window_ctx<N>(p, blockIdx.x * WPB + wl);
+  // ticket ring: group G(i) of iteration i; G(0) = blockIdx.x, G(i >= 1) = gridDim.x + ticket * queues + queue
+  // A ticket is published at the end of an iteration and may be read once a barrier has passed: at the
+  // prefetch point of the next iteration when a whole sub-transform lies before it (F = 2: two groups
+  // ahead, the smallest tail), else at the top of the iteration after the next (three groups ahead; also
+  // used at F = 4, where the window arithmetic at the prefetch point would spill).
+  constexpr bool kLateRead = (F == 2);
+  constexpr int LOOK = kLateRead ? 2 : 3;
+  unsigned *ring = reinterpret_cast<unsigned *>(red + 2 * (kBlock / 64));
+  const unsigned n_groups = (p.n_win + WPB - 1) / WPB;
+  const unsigned my_queue = blockIdx.x % kTicketQueues;
+  unsigned *const my_ticket = p.ticket + my_queue * kTicketStride;
+  if (tid == 0) {
+    for (int s2 = 1; s2 < LOOK; s2++) ring[s2] = gridDim.x + atomicAdd(my_ticket, 1u) * kTicketQueues + my_queue;
+  }
+  __syncthreads();
+  unsigned cur_g = blockIdx.x;
+  WinCtx cur = window_ctx<N>(p, cur_g * WPB + wl);
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
   float2 cc[CONST_OFF ? R : 1];
   float cwin[CONST_OFF ? R : 1];
@@ -552,8 +576,10 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
   bool prev_nan = false, have_prev = false;
   int par = 0;
 
-  for (unsigned base = blockIdx.x * WPB; base < p.n_win; base += step) {
+  for (unsigned it = 0; cur_g < n_groups; it++) {
     LORA_STAMP(0);
+    unsigned tk = 0;
+    if (tid == 0) tk = atomicAdd(my_ticket, 1u);      // G(it + LOOK); lands while this group is processed
     // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
     float2 c[R];
     float w[R];
@@ -574,7 +600,12 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
       }
     }
-    const WinCtx nxt = window_ctx<N>(p, cur.win_id + step);
+    unsigned nxt_g = 0;
+    WinCtx nxt;
+    if constexpr (!kLateRead) {
+      nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);   // G(it + 1); uniform: scalar window arithmetic
+      nxt = window_ctx<N>(p, nxt_g * WPB + wl);
+    }
 
     // ---- dechirp + window: x[k] <-> sample n = tw + k*T -----------------------------------
     float2 x[R];
@@ -602,6 +633,10 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
       if (rr == F - 1) {
         // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
         asm volatile("" ::: "memory");
+        if constexpr (kLateRead) {
+          nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);
+          nxt = window_ctx<N>(p, nxt_g * WPB + wl);
+        }
         const float2 *__restrict__ src = p.iq + ((LORA_ABL & 64) ? 0 : nxt.pos) + tw;   // ABL 64: every window reads window 0 (L2)
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -638,7 +673,8 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
     }
     prev_best = reduce_partial(best, par);
     prev = cur; prev_nan = bin0_nan; have_prev = true;
-    cur = nxt;
+    if (tid == 0) ring[it % LOOK] = gridDim.x + tk * kTicketQueues + my_queue;   // read LOOK - 1 iterations from now, behind barriers
+    cur = nxt; cur_g = nxt_g;
     par ^= 1;
   }
   if (have_prev) {
@@ -657,7 +693,7 @@ template <int LOGN, int F>
 constexpr size_t demod_lds_bytes() {
   constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
   return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
-         2 * (kBlock / 64) * sizeof(Best);
+         2 * (kBlock / 64) * sizeof(Best) + 16 /* ticket ring */;
 }
 template <int LOGN>
 constexpr int demod_wpb() { return kBlock / ((1 << LOGN) / plan_points(LOGN)); }
