@@ -20,7 +20,7 @@ struct lora_hip_demod {
   float2 *d_up = nullptr, *d_down = nullptr;
   float *d_win = nullptr;
   float2 *d_tw = nullptr;       // the pass tables
-  size_t tw_off[3] = {0, 0, 0};
+  size_t tw_off[4] = {0, 0, 0, 0};
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
   void *d_desc = nullptr; size_t cap_desc = 0;
@@ -32,7 +32,7 @@ struct lora_hip_demod {
   char hip_err[256] = {0};
   const char *kernel_name = "";
   int num_cu = 256;
-  unsigned blocks_per_cu = LORA_MIN_WAVES;
+  unsigned blocks_per_cu = 0;      // 0: the kernel variant's own choice (LORA_HIP_BLOCKS_PER_CU overrides)
 };
 
 namespace {
@@ -58,12 +58,13 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
 #define LORA_NO_CONST 0   // developer knob: 1 = never use the register-resident-taps variant
 #endif
 typedef void (*kernel_fn)(const KParams);
-struct Variant { kernel_fn fn, fn_const; size_t lds; int wpb; const char *name; };
+struct Variant { kernel_fn fn, fn_const; size_t lds; int wpb, threads, blocks_per_cu; const char *name; };
 
 template <int LOGN, int F>
 Variant make_variant(const char *name) {
   return Variant{&lora_hip::demod_kernel<LOGN, F, false>, &lora_hip::demod_kernel<LOGN, F, true>,
-                 lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN>(), name};
+                 lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN>(), lora_hip::block_threads(LOGN),
+                 lora_hip::min_waves(LOGN) * 4 / (lora_hip::block_threads(LOGN) / 64), name};
 }
 
 #define LORA_VARIANTS_SF(SF) \
@@ -87,10 +88,10 @@ int launch(lora_hip_demod *h, KParams &p) {
   if (p.n_win == 0) return LORA_HIP_OK;
   // persistent workgroups: at most blocks_per_cu per CU, each walks the windows grid-stride
   unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
-  const unsigned resident = (unsigned)h->num_cu * h->blocks_per_cu;
+  const unsigned resident = (unsigned)h->num_cu * (h->blocks_per_cu ? h->blocks_per_cu : (unsigned)v.blocks_per_cu);
   if (blocks > resident) blocks = resident;
 #if LORA_STAMPS
-  const size_t ndbg = (size_t)blocks * (lora_hip::kBlock / 64) * 8;
+  const size_t ndbg = (size_t)blocks * (v.threads / 64) * 8;
   if (!h->d_dbg) (void)hipMalloc((void **)&h->d_dbg, (size_t)h->num_cu * 8 * 4 * 8 * sizeof(unsigned long long));
   (void)hipMemsetAsync(h->d_dbg, 0, ndbg * sizeof(unsigned long long), h->stream);
   p.dbg = h->d_dbg;
@@ -102,7 +103,7 @@ int launch(lora_hip_demod *h, KParams &p) {
   }
   // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
   const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
-  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(lora_hip::kBlock), v.lds, h->stream, p);
+  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), v.lds, h->stream, p);
 #if LORA_STAMPS
   {
     std::vector<unsigned long long> hd(ndbg);
@@ -110,7 +111,7 @@ int launch(lora_hip_demod *h, KParams &p) {
     (void)hipStreamSynchronize(h->stream);
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
-    const double nw = (double)blocks * (lora_hip::kBlock / 64);
+    const double nw = (double)blocks * (v.threads / 64);
     {   // spread of per-wave lifetimes (100 MHz ticks): static grid-stride shares, so equal work per wave
       std::vector<double> life;
       for (size_t w = 0; w < ndbg / 8; w++) life.push_back((double)hd[w * 8 + 7]);
@@ -366,7 +367,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
     p.out_idx = reinterpret_cast<unsigned short *>(h->d_out + n_win * 4);     // packed behind this call's values
   }
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
-  for (int ps = 0; ps < 3; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
+  for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
   if ((rc = launch(h, p)) != LORA_HIP_OK) return rc;
   if (!out_dev) {

@@ -26,7 +26,7 @@ struct KParams {
   unsigned long long n_samples;
   const float2 *up, *down;      // 2N-entry chirp tables (demod_impl.cc:92-101)
   const float *win;             // N Kaiser taps (demod_impl.cc:85)
-  const void *twp[3];           // per pass ps>=1: merged twiddles: float2 [F][r-1][NS] (LDS) or [F][NS] (base only)
+  const void *twp[4];           // per pass ps>=1: merged twiddles: float2 [F][r-1][NS] (LDS) or [F][NS] (base only)
   const void *desc;             // lora_win_desc[n_win] or nullptr for the strided form
   unsigned long long pos0, stride;
   unsigned off0, off_step, kind;
@@ -155,8 +155,13 @@ template <> struct Dft<16> {
 
 // ---- geometry ---------------------------------------------------------------------------
 // Radix plan per spreading factor: N = product of the pass radices; R = points per thread.
-constexpr int plan_points(int logn) { return logn == 9 ? 8 : 16; }
-constexpr int plan_passes(int logn) { return logn <= 8 ? 2 : 3; }
+#ifndef LORA_SF12_R8
+#define LORA_SF12_R8 0   // experiment: SF12 with 8 points per thread, 512-thread workgroups, 8.8.8.8 and 4 waves per SIMD
+                         // (121 VGPRs, no spills): correct, but 27 % slower than 16 points per thread (0.545 vs 0.40 ms at F=2):
+                         // one more LDS exchange per transform outweighs the even wave count
+#endif
+constexpr int plan_points(int logn) { return (logn == 9 || (LORA_SF12_R8 && logn == 12)) ? 8 : 16; }
+constexpr int plan_passes(int logn) { return logn <= 8 ? 2 : (LORA_SF12_R8 && logn == 12) ? 4 : 3; }
 constexpr int plan_radix(int logn, int ps) {
   switch (logn) {
     case 6:  return ps == 0 ? 16 : 4;
@@ -165,12 +170,12 @@ constexpr int plan_radix(int logn, int ps) {
     case 9:  return 8;
     case 10: return ps == 0 ? 16 : 8;
     case 11: return ps == 2 ? 8 : 16;
-    default: return 16;   // 12
+    default: return LORA_SF12_R8 ? 8 : 16;   // 12
   }
 }
 constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++) v *= plan_radix(logn, i); return v; }
 
-constexpr int kBlock = 256;
+constexpr int block_threads(int logn) { return (LORA_SF12_R8 && logn == 12) ? 512 : 256; }
 constexpr unsigned kTicketQueues = 8, kTicketStride = 32;   // 8 counters, 128 bytes apart
 #ifndef LORA_ABL
 #define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax, 32 no LDS exchanges (SF12), 64 IQ from L2
@@ -193,6 +198,7 @@ constexpr unsigned kTicketQueues = 8, kTicketStride = 32;   // 8 counters, 128 b
 #ifndef LORA_MIN_WAVES
 #define LORA_MIN_WAVES 3
 #endif
+constexpr int min_waves(int logn) { return (LORA_SF12_R8 && logn == 12) ? 4 : LORA_MIN_WAVES; }
 
 // Twiddle table of pass ps >= 1 (merged with the zero-padding twist, see fft_pass).  Vector loads
 // return to the registers at only ~32 B/clk per CU (measured: TD busy 84 % with tables in L2), so
@@ -432,7 +438,8 @@ __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned wi
 //   * otherwise they are requested first thing in iteration i, and the reduction + store of
 //     window i-1 runs while they are in flight.
 template <int LOGN, int F, bool CONST_OFF>
-__global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KParams p) {
+__global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_kernel(const KParams p) {
+  constexpr int kBlock = block_threads(LOGN);
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R, WPB = kBlock / T;
   constexpr int PADN = N + N / 16;
   static_assert(T >= 1 && T <= kBlock && WPB >= 1, "geometry");
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
   // thread's butterflies, per sub-transform, for the whole launch
   constexpr int NPS = plan_passes(LOGN), NSL = plan_ns(LOGN, NPS - 1), NBL = R / plan_radix(LOGN, NPS - 1);
   constexpr bool kBaseRegs = !pass_table_in_lds(LOGN, F, NPS - 1);
-  constexpr bool kDigits = (LOGN == 12 && LORA_SF12_DIGITS);
+  constexpr bool kDigits = (LOGN == 12 && LORA_SF12_DIGITS && !LORA_SF12_R8);
   float2 wb[kBaseRegs ? F * NBL : 1];
   if constexpr (kBaseRegs) {
     const float2 *__restrict__ tab = reinterpret_cast<const float2 *>(p.twp[NPS - 1]);
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 #endif
         }
       }
-      if constexpr (LOGN == 12 && LORA_SF12_DIGITS) fft_sf12<F>(v, tile, lds_tw, tw, wb[rr], rr LORA_STAMP_ARGS);
+      if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[rr], rr LORA_STAMP_ARGS);
       else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? rr * NBL : 0), rr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
       if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
         const float mag = magsq(v[k]);
         if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);      // thread 0 holds bin 0 in both mappings
         // bin held by register k: generic Stockham tw + k*T; SF12 digit mapping (tw>>4) + 16*(tw&15) + 256*k
-        const int kout = (LOGN == 12 && LORA_SF12_DIGITS) ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
+        const int kout = kDigits ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
 #if LORA_ABL & 16
         b.v += mag;
 #else
@@ -691,11 +698,12 @@ __global__ __launch_bounds__(kBlock, LORA_MIN_WAVES) void demod_kernel(const KPa
 
 template <int LOGN, int F>
 constexpr size_t demod_lds_bytes() {
+  constexpr int kBlock = block_threads(LOGN);
   constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
   return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
          2 * (kBlock / 64) * sizeof(Best) + 16 /* ticket ring */;
 }
 template <int LOGN>
-constexpr int demod_wpb() { return kBlock / ((1 << LOGN) / plan_points(LOGN)); }
+constexpr int demod_wpb() { return block_threads(LOGN) / ((1 << LOGN) / plan_points(LOGN)); }
 
 }  // namespace lora_hip
