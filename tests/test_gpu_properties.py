@@ -161,3 +161,33 @@ def test_random_sweep_cfg3(g):
                 total += count; flips += int(np.count_nonzero(gi != ri))
             h.close()
     print(f"cfg3 sweep: {total} windows, {flips} sub-margin argmax differences")
+
+
+@pytest.mark.parametrize("sf,f", [(7, 2), (10, 1), (12, 2)])
+def test_back_to_back_async_launches_on_one_stream(sf, f, g):
+    """Device-resident buffers, LORA_HIP_ASYNC, several launches queued on the caller's stream before any
+    synchronisation (the bench's pattern): the persistent kernel's ticket counters are reset in stream order,
+    so every launch sees every window exactly once.  Launch sizes straddle the resident grid (fewer windows
+    than workgroups, a few per workgroup, many)."""
+    import torch
+    n = 1 << sf
+    rng = np.random.default_rng(sf)
+    n_win = 4096 if sf <= 10 else 1500
+    iq_h = (rng.standard_normal(n_win * n) + 1j * rng.standard_normal(n_win * n)).astype(np.complex64)
+    iq = torch.from_numpy(iq_h).cuda()
+    h = g.HipDemod(sf, f, cases.BETA)
+    ref_idx, ref_val = h.batch_strided(iq_h, 0, n, n_win)                 # synchronous, host buffers
+    s = torch.cuda.Stream()
+    h.set_stream(s.cuda_stream)
+    counts = [n_win, 3, n_win // 2, 1, n_win - 7, 700]
+    outs = []
+    for c in counts:
+        oi = torch.full((c,), -1, dtype=torch.int16, device="cuda"); ov = torch.full((c,), -7.0, device="cuda")
+        s.wait_stream(torch.cuda.current_stream())
+        h.batch_strided(iq, 0, n, c, out_idx=oi, out_val=ov, async_=True)
+        outs.append((oi, ov))
+    s.synchronize()
+    for c, (oi, ov) in zip(counts, outs):
+        assert np.array_equal(oi.cpu().numpy().view(np.uint16), ref_idx[:c]), c
+        assert np.array_equal(ov.cpu().numpy().view(np.uint32), ref_val[:c].view(np.uint32)), c
+    h.close()
