@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3] and configs[4] at full size on one MI355X, checked against the oracle.
+
+  configs[3]: 1024 independent channelised captures, SF10 fft_factor 2, one 256-symbol packet each
+              (283 008 samples, 2.16 GiB in total), sharded over 8 ranks (simulated in this process).
+  configs[4]: one 1-hour capture at 125 kS/s (4.5e8 samples, 3.35 GiB), SF9 fft_factor 2, Poisson arrivals
+              (mean 1 packet/s), 16..128 symbols per packet, time-sharded into 8 segments (design A).
+Prints timings and the comparison; the oracle runs on one host core (it is the checker, not the product).
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from importlib import import_module
+import numpy as np
+import gr_lora_amd as g
+import oracle
+shard = import_module("gr-lora_amd.shard")
+BETA, SYNC = 25.0, 0x12
+
+
+def cfg3(n_cap=1024, world=8, check_every=16):
+    sf, f, n = 10, 2, 1024
+
+    def load(cid):
+        syms = oracle.random_symbols(sf, 256, 4000 + cid)
+        return np.concatenate([oracle.modulate(sf, syms, SYNC), np.zeros(4 * n, np.complex64)])
+
+    caps = [load(c) for c in range(n_cap)]                      # 2.2 GiB of host memory, generated up front
+    t0 = time.perf_counter()
+    merged = {}
+    for rank in range(world):
+        lo, hi = shard.my_range(n_cap, rank, world)
+        blk = g.demod(sf, False, BETA, f)                       # one block per rank, re-created per capture below
+        blk.close()
+        merged.update(shard.demod_captures(range(lo, hi), lambda c: caps[c], lambda: g.demod(sf, False, BETA, f)))
+    dt = time.perf_counter() - t0
+    out = shard.gather_pdus(merged, n_cap)
+    n_sym = sum(len(p) for c in out for p in c)
+    d = oracle.Demod(sf, False, BETA, f)
+    bad = 0
+    for cid in range(0, n_cap, check_every):
+        ref = d.stream(caps[cid])[0]
+        bad += [p.tolist() for p in out[cid]] != [p.tolist() for p in ref]
+    print(f"configs[3]: {n_cap} captures x {len(caps[0])} samples (SF10 F2), 8 simulated ranks on one GPU: {dt:.2f} s "
+          f"({n_cap / dt:.0f} captures/s, {sum(len(c) for c in caps) * 8 / dt / 1e9:.2f} GB/s of IQ from host memory), "
+          f"{sum(len(c) for c in out)} PDUs / {n_sym} symbols; {n_cap // check_every} captures checked against the oracle: "
+          f"{bad} differ", flush=True)
+
+
+def cfg4(seconds=3600.0, world=8):
+    sf, f, n = 9, 2, 512
+    rng = np.random.default_rng(5)
+    total = int(125e3 * seconds)
+    cap = np.zeros(total, np.complex64)
+    pos, n_tx = 0, 0
+    while True:
+        pos += int(rng.exponential(1.0) * 125e3)
+        ns = int(rng.integers(16, 129))
+        frame = oracle.modulate(sf, oracle.random_symbols(sf, ns, 5 * 7919 + n_tx), SYNC)
+        if pos + len(frame) + 4 * n > total:
+            break
+        cap[pos:pos + len(frame)] = frame
+        pos += len(frame); n_tx += 1
+    print(f"configs[4]: {total} samples ({total * 8 / 2**30:.2f} GiB), {n_tx} packets", flush=True)
+    t0 = time.perf_counter()
+    blk = g.demod(sf, False, BETA, f)
+    seq = blk.work(cap)
+    st = blk.stats
+    blk.close()
+    t_seq = time.perf_counter() - t0
+    print(f"  sequential block: {t_seq:.2f} s, {len(seq)} PDUs, {st['calls']} calls, {st['launches']} launches, "
+          f"{st['windows']} GPU windows ({st['calls'] / t_seq / 1e6:.2f} M calls/s incl. the host-to-device copy)", flush=True)
+    t0 = time.perf_counter()
+    sweep = shard.HipSweeper(sf, f, BETA)
+    parts = [shard.sweep_segment(sweep, cap, sf, q0, q1) for q0, q1 in shard.lattice_partition(len(cap), sf, world)]
+    sweep.close()
+    t_sweep = time.perf_counter() - t0
+    runs = shard.merge_sweeps(parts, sf)
+    t0 = time.perf_counter()
+    blk = g.demod(sf, False, BETA, f)
+    for start, idx, val in runs:
+        blk.preload(start, idx, val)
+    da = blk.work(cap)
+    st = blk.stats
+    blk.close()
+    t_rep = time.perf_counter() - t0
+    same = [p.tolist() for p in da] == [p.tolist() for p in seq]
+    print(f"  design A, {world} segments swept one after the other on this GPU: sweep {t_sweep:.2f} s "
+          f"({sum(len(r[1]) for r in runs)} windows, 16 phases; /{world} per GPU when sharded), replay {t_rep:.2f} s "
+          f"({st['launches']} launches); PDUs identical to the sequential block: {same}", flush=True)
+    t0 = time.perf_counter()
+    ref = oracle.Demod(sf, False, BETA, f).stream(cap)[0]
+    t_or = time.perf_counter() - t0
+    same_or = [p.tolist() for p in seq] == [p.tolist() for p in ref]
+    ndiff = sum(1 for a, b in zip(seq, ref) if a.tolist() != b.tolist()) + abs(len(seq) - len(ref))
+    print(f"  oracle on one host core: {t_or:.1f} s, {len(ref)} PDUs; identical to the GPU block: {same_or}"
+          + ("" if same_or else f" ({ndiff} PDUs differ)"), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["3", "4"]
+    if "3" in which:
+        cfg3()
+    if "4" in which:
+        cfg4()
