@@ -67,8 +67,12 @@ struct lora_demod_core {
   std::vector<unsigned short> d_argmax_history, d_sfd_history;
   unsigned d_sync_recovery_counter = 0;
   std::vector<unsigned short> d_symbols;
-  // stream framing: buf holds stream samples [base, base + buf.size()); pos = read index
+  // stream framing: the samples [base, base + total()) of the framed stream are buf (carried over from
+  // earlier calls) followed, during a work() call, by that call's input, which is never copied on the
+  // host: only the GPU reads samples, the host keeps what a later call may still need; pos = read index
   std::vector<lora_c32> buf;
+  const lora_c32 *cur_in = nullptr; size_t cur_n = 0;
+  size_t total() const { return buf.size() + cur_n; }
   uint64_t base = 0, pos = 0;
   // GPU result caches
   std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
@@ -83,7 +87,7 @@ struct lora_demod_core {
 
 namespace {
 
-constexpr size_t kMaxSpec = 1u << 16, kMaxRuns = 48;
+constexpr size_t kMaxSpec = 1u << 16, kReadSpec = 2048, kMaxRuns = 48;
 
 int fail(lora_demod_core *c, int rc, const char *what) {
   c->err = std::string(what) + ": " + lora_hip_strerror(rc);
@@ -93,7 +97,7 @@ int fail(lora_demod_core *c, int rc, const char *what) {
 
 int ensure_staged(lora_demod_core *c) {
   if (c->staged) return LORA_HIP_OK;
-  int rc = lora_hip_demod_stage_iq(c->hip, c->buf.data(), c->buf.size());
+  int rc = lora_hip_demod_stage_iq2(c->hip, c->buf.data(), c->buf.size(), c->cur_in, c->cur_n);
   if (rc) return fail(c, rc, "stage_iq");
   c->staged = true;
   return LORA_HIP_OK;
@@ -105,7 +109,7 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
   if (rc) return rc;
   r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
   r.idx.assign(count, 0); r.val.assign(count, 0.f);
-  rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->buf.size(), start - c->base, stride, count, off0, off_step,
+  rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->total(), start - c->base, stride, count, off0, off_step,
                                     kind, r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
   if (rc) { r.idx.clear(); r.val.clear(); return fail(c, rc, "batch_strided"); }
   c->n_windows += count; c->n_launches++;
@@ -133,12 +137,14 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
     else r++;
   }
   if (c->up_runs.size() >= kMaxRuns) c->up_runs.erase(c->up_runs.begin());
-  // Sweep this (lattice phase, offset) to the end of the buffered samples: a window costs the GPU
-  // nanoseconds, a launch and its synchronisation tens of microseconds, and the same lattice tends to
-  // come back after later packets (there are only 16 phases).
-  const uint64_t end = c->base + c->buf.size();
+  // Sweep this (lattice phase, offset) far ahead: a window costs the GPU nanoseconds, a launch and its
+  // synchronisation tens of microseconds, and the same lattice tends to come back after later packets
+  // (there are only 16 phases).  A header/payload lattice ends with its packet, so it gets a shorter sweep
+  // than a preamble search.
+  const uint64_t end = c->base + c->total();
   const size_t avail = (size_t)((end - pos - n) / n + 1);
-  const size_t want = kMaxSpec;
+  const bool reading = (c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD);
+  const size_t want = reading ? kReadSpec : kMaxSpec;
   c->up_runs.emplace_back();
   int rc = launch_run(c, c->up_runs.back(), pos, n, avail < want ? avail : want, off, 0, LORA_WIN_UP);
   if (rc) { c->up_runs.pop_back(); return rc; }
@@ -152,7 +158,7 @@ int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short 
   size_t k;
   if (!c->sfd_run.find(call_pos + off, off, n, &k)) {
     // cover the rest of this call and the following calls of the sync attempt
-    const uint64_t end = c->base + c->buf.size();
+    const uint64_t end = c->base + c->total();
     const uint64_t first = call_pos + off;
     size_t avail = (size_t)((end - first - n) / step + 1);
     size_t want = (size_t)OVERLAP_FACTOR * 10 + OVERLAP_FACTOR;
@@ -298,21 +304,33 @@ void lora_demod_core_destroy(lora_demod_core_t *c) {
 
 int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, lora_pdu_cb cb, void *user) {
   if (!c || (!in && n_in)) return LORA_HIP_EINVAL;
-  if (n_in) { c->buf.insert(c->buf.end(), in, in + n_in); c->staged = false; }
+  c->cur_in = in; c->cur_n = n_in;
+  if (n_in) c->staged = false;
   const uint64_t need = (uint64_t)c->d_num_symbols + (uint64_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1;
-  while (c->base + c->buf.size() >= c->pos + need) {
+  int rc = LORA_HIP_OK;
+  while (c->base + c->total() >= c->pos + need) {
     unsigned consumed = 0;
-    int rc = general_work(c, cb, user, &consumed);
-    if (rc) return rc;
+    rc = general_work(c, cb, user, &consumed);
+    if (rc) break;
     c->pos += consumed;                                             // consume_each, :443
   }
-  // drop what can never be read again; cached runs keep absolute positions
-  if (c->pos > c->base) {
-    const size_t drop = (size_t)(c->pos - c->base);
-    c->buf.erase(c->buf.begin(), c->buf.begin() + (drop < c->buf.size() ? drop : c->buf.size()));
-    c->base += drop;
-    c->staged = false;
-  }
+  // keep what can still be read, [pos, end), as the next call's carry; cached runs keep absolute positions
+  try {
+    const uint64_t carry_end = c->base + c->buf.size();
+    if (n_in == 0) {
+      c->buf.erase(c->buf.begin(), c->buf.begin() + (size_t)(c->pos - c->base));
+    } else if (c->pos >= carry_end) {
+      const size_t skip = (size_t)(c->pos - carry_end);             // pos <= end: a call never consumes past need
+      c->buf.assign(in + (skip < n_in ? skip : n_in), in + n_in);
+    } else {
+      c->buf.erase(c->buf.begin(), c->buf.begin() + (size_t)(c->pos - c->base));
+      c->buf.insert(c->buf.end(), in, in + n_in);
+    }
+  } catch (const std::bad_alloc &) { rc = rc ? rc : LORA_HIP_ENOMEM; }
+  c->base = c->pos > c->base ? c->pos : c->base;
+  c->cur_in = nullptr; c->cur_n = 0;
+  c->staged = false;
+  if (rc) return rc;
   return LORA_HIP_OK;
 }
 

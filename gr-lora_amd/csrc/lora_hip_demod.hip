@@ -296,16 +296,22 @@ int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream) {
   return LORA_HIP_OK;
 }
 
-int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples) {
-  if (!h || (!iq && n_samples)) return LORA_HIP_EINVAL;
+int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a, const lora_c32 *b, size_t n_b) {
+  if (!h || (!a && n_a) || (!b && n_b)) return LORA_HIP_EINVAL;
   HIP_TRY(h, hipSetDevice(h->device));
   h->staged_n = 0;
-  int rc = grow(h, &h->d_iq, &h->cap_iq, n_samples ? n_samples : 1);
+  const size_t n = n_a + n_b;
+  int rc = grow(h, &h->d_iq, &h->cap_iq, n ? n : 1);
   if (rc != LORA_HIP_OK) return rc;
-  if (n_samples) HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));     // the host buffer may be reused by the caller
-  h->staged_n = n_samples;
+  if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (n_b) HIP_TRY(h, hipMemcpyAsync(h->d_iq + n_a, b, n_b * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));     // the host buffers may be reused by the caller
+  h->staged_n = n;
   return LORA_HIP_OK;
+}
+
+int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples) {
+  return lora_hip_demod_stage_iq2(h, iq, n_samples, nullptr, 0);
 }
 
 unsigned lora_hip_demod_sf(const lora_hip_demod_t *h) { return h ? h->sf : 0; }

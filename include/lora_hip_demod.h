@@ -121,6 +121,11 @@ LORA_HIP_API int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c3
  * batch calls (flag LORA_HIP_IQ_STAGED) can sweep them without another host-to-device copy.
  * This is what replaces the scheduler-owned input buffer of general_work (:155). */
 LORA_HIP_API int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples);
+/* The same for a capture that lies in two host pieces, staged back to back (a then b): the samples a
+ * block carried over from its previous call (set_history, :103) and the new input items, without
+ * joining them on the host first. */
+LORA_HIP_API int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a,
+                                          const lora_c32 *b, size_t n_b);
 
 /* geometry of the handle */
 LORA_HIP_API unsigned lora_hip_demod_sf(const lora_hip_demod_t *h);
