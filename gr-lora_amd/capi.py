@@ -28,7 +28,7 @@ EXPORTS = (
     # include/lora_demod_core.h
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
-    "lora_demod_core_last_error", "lora_demod_core_preload",
+    "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset",
 )
 
 PDU_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint16), C.c_size_t)
@@ -85,6 +85,7 @@ def lib():
         getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = u64
     L.lora_demod_core_state.argtypes = [vp]; L.lora_demod_core_state.restype = i
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
+    L.lora_demod_core_reset.argtypes = [vp]; L.lora_demod_core_reset.restype = i
     L.lora_demod_core_preload.argtypes = [vp, u64, sz, vp, vp]; L.lora_demod_core_preload.restype = i
     _lib = L
     return L

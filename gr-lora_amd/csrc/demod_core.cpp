@@ -296,6 +296,25 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   return LORA_HIP_OK;
 }
 
+int lora_demod_core_reset(lora_demod_core_t *c) {
+  if (!c) return LORA_HIP_EINVAL;
+  // back to the state of a freshly made block (:77-88, :103): same tables and GPU buffers, new stream
+  c->d_state = LORA_S_RESET;
+  c->d_overlaps = OVERLAP_DEFAULT; c->d_offset = 0;
+  c->d_power = .000000001f; c->d_squelched = false;
+  c->d_preamble_idx = 0; c->d_sfd_idx = 0;
+  c->d_argmax_history.clear(); c->d_sfd_history.clear(); c->d_symbols.clear();
+  c->d_sync_recovery_counter = 0;
+  c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
+  c->cur_in = nullptr; c->cur_n = 0;
+  c->base = 0; c->pos = 0;
+  c->up_runs.clear(); c->pre_runs.clear(); c->sfd_run = Run();
+  c->staged = false;
+  c->n_calls = 0; c->n_windows = 0; c->n_launches = 0;
+  c->err.clear();
+  return LORA_HIP_OK;
+}
+
 void lora_demod_core_destroy(lora_demod_core_t *c) {
   if (!c) return;
   lora_hip_demod_destroy(c->hip);

@@ -76,6 +76,13 @@ class demod:
         n = min(int(capi.lib().lora_demod_core_calls(self._h)), len(self._trace))
         return self._trace[:n]
 
+    def reset(self):
+        """Start a new, independent stream (lora_demod_core_reset): same as a freshly made block."""
+        rc = capi.lib().lora_demod_core_reset(self._h)
+        if rc:
+            raise capi.LoraHipError(rc)
+        self._pending = []
+
     def preload(self, start, idx, val):
         """lora_demod_core_preload: up-path results (offset 0) of the windows starting at framed-stream
         index start + k*N, produced ahead of time (shard.sharded_detect_sweep)."""

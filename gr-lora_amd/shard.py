@@ -37,13 +37,20 @@ def demod_captures(capture_ids, load_capture, make_block):
     """Demodulate the captures of this rank.  load_capture(id) -> complex64 array;
     make_block() -> an object with work(samples) -> list of u16 arrays (gr-lora_amd.demod or any
     stand-in with the same interface).  Returns {id: [pdu, ...]}."""
-    out = {}
+    out, blk = {}, None
     for cid in capture_ids:
-        blk = make_block()
+        if blk is None:
+            blk = make_block()
         out[cid] = [np.asarray(p, np.uint16) for p in blk.work(load_capture(cid))]
-        close = getattr(blk, "close", None)
-        if close:
-            close()
+        if hasattr(blk, "reset"):
+            blk.reset()                 # same block, fresh stream: keeps the tables and GPU buffers
+        else:
+            close = getattr(blk, "close", None)
+            if close:
+                close()
+            blk = None
+    if blk is not None and hasattr(blk, "close"):
+        blk.close()
     return out
 
 

@@ -49,6 +49,11 @@ typedef struct {
 LORA_HIP_API int lora_demod_core_create(lora_demod_core_t **c, int device, unsigned spreading_factor,
                                         int low_data_rate, float beta, unsigned fft_factor);
 LORA_HIP_API void lora_demod_core_destroy(lora_demod_core_t *c);
+/* Start a new, independent stream on the same block: everything is as after create (state S_RESET,
+ * empty histories, 3N-1 zeros of history, counters and trace position at zero; a trace buffer stays set),
+ * but the tables and the GPU buffers are kept.  Equivalent to destroying the block and making it again
+ * with the same arguments; meant for demodulating many captures one after the other. */
+LORA_HIP_API int lora_demod_core_reset(lora_demod_core_t *c);
 
 /* Feed n_in new samples (host memory).  Runs every general_work call that GNU Radio's scheduler
  * could run with the samples fed so far (a call needs N + history-1 = 4N-1 samples from its read
