@@ -86,7 +86,7 @@ int launch(lora_hip_demod *h, KParams &p) {
   Variant v;
   if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
   if (p.n_win == 0) return LORA_HIP_OK;
-  // persistent workgroups: at most blocks_per_cu per CU, each walks the windows grid-stride
+  // persistent workgroups: at most blocks_per_cu per CU; they share the window groups through ticket counters
   unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
   const unsigned resident = (unsigned)h->num_cu * (h->blocks_per_cu ? h->blocks_per_cu : (unsigned)v.blocks_per_cu);
   if (blocks > resident) blocks = resident;
@@ -112,7 +112,7 @@ int launch(lora_hip_demod *h, KParams &p) {
     double sum[8] = {0};
     for (size_t i = 0; i < ndbg; i++) sum[i % 8] += (double)hd[i];
     const double nw = (double)blocks * (v.threads / 64);
-    {   // spread of per-wave lifetimes (100 MHz ticks): static grid-stride shares, so equal work per wave
+    {   // spread of per-wave lifetimes (100 MHz ticks)
       std::vector<double> life;
       for (size_t w = 0; w < ndbg / 8; w++) life.push_back((double)hd[w * 8 + 7]);
       std::sort(life.begin(), life.end());
