@@ -72,8 +72,11 @@ def compare_with_oracle(g, sf, f, ldr, cap, chunks=None, name=""):
         if not np.isin(pre_rows, flips).any():
             a = np.concatenate(got) if got else np.zeros(0, np.uint16)
             b = np.concatenate(ref_pdus) if ref_pdus else np.zeros(0, np.uint16)
-            assert len(a) == len(b) == len(read_rows), name
-            assert np.array_equal(a[~flipped_syms], b[~flipped_syms]), f"{name}: PDU symbols differ"
+            # symbols are pushed one per READ_* call, in order; a packet still being read when the capture
+            # ends has rows but no PDU
+            assert len(a) == len(b) <= len(read_rows), name
+            keep = ~flipped_syms[:len(a)]
+            assert np.array_equal(a[keep], b[keep]), f"{name}: PDU symbols differ"
         return dict(stats, same_path=True, flips=int(flips.size), pdus=len(got),
                     pdus_identical=bool(len(got) == len(ref_pdus) and all(np.array_equal(x, y) for x, y in zip(got, ref_pdus))))
     # The call sequences part ways at `first`: legitimate only if a window that feeds the decision
