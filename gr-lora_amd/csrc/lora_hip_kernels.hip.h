@@ -578,6 +578,10 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
 #pragma unroll
     for (int k = 0; k < R; k++) nx[k] = src[k * T];
   }
+  // The store of window i is deferred into window i + 1 when the window spans several waves (the partials
+  // meet behind the next window's barriers) and, measured, whenever F > 1; at F = 1 with a window inside one
+  // wave storing at once frees the registers of the deferred state (SF7/SF8: +28 % / +41 %).
+  constexpr bool kDeferStore = (T > 64) || (F > 1);
   WinCtx prev = cur;
   Best prev_best = {-1.0f, 0};
   bool prev_nan = false, have_prev = false;
@@ -657,7 +661,9 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
       if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[rr], rr LORA_STAMP_ARGS);
       else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? rr * NBL : 0), rr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
-      if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
+      if constexpr (kDeferStore) {
+        if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
+      }
       LORA_STAMP(4);
       // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
       // lowest index of this thread's maximum for this rr
@@ -678,8 +684,12 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
       asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
     }
-    prev_best = reduce_partial(best, par);
-    prev = cur; prev_nan = bin0_nan; have_prev = true;
+    if constexpr (kDeferStore) {
+      prev_best = reduce_partial(best, par);
+      prev = cur; prev_nan = bin0_nan; have_prev = true;
+    } else {
+      combine_store(cur, reduce_partial(best, par), bin0_nan, par);   // a window inside one wave is final already
+    }
     if (tid == 0) ring[it % LOOK] = gridDim.x + tk * kTicketQueues + my_queue;   // read LOOK - 1 iterations from now, behind barriers
     cur = nxt; cur_g = nxt_g;
     par ^= 1;
