@@ -452,7 +452,9 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
 
   const int tid = threadIdx.x;
   const int tw = tid % T;          // thread within its window
-  const int wl = tid / T;          // window within the workgroup
+  // window within the workgroup; wave-uniform when a window fills whole waves, which keeps the window
+  // arithmetic (64-bit positions, validity) in scalar registers
+  const int wl = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
   float2 *tile = smem + wl * PADN;
 
   // once per workgroup: small twiddle tables -> LDS (visible after the first barrier of pass 0)
