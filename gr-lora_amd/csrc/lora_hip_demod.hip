@@ -97,7 +97,7 @@ int launch(lora_hip_demod *h, KParams &p) {
   p.dbg = h->d_dbg;
 #endif
   {
-    hipError_t em = hipMemsetAsync(h->d_ticket, 0, lora_hip::kTicketQueues * lora_hip::kTicketStride * sizeof(unsigned), h->stream);
+    hipError_t em = hipMemsetAsync(h->d_ticket, 0, lora_hip::kWaveTicketQueues * lora_hip::kTicketStride * sizeof(unsigned), h->stream);
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
     p.ticket = h->d_ticket;
   }
@@ -259,7 +259,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_down, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_win, n * sizeof(float)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
-  if (hipMalloc((void **)&h->d_ticket, lora_hip::kTicketQueues * lora_hip::kTicketStride * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_ticket, lora_hip::kWaveTicketQueues * lora_hip::kTicketStride * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);

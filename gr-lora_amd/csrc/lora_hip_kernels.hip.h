@@ -176,7 +176,7 @@ constexpr int plan_radix(int logn, int ps) {
 constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++) v *= plan_radix(logn, i); return v; }
 
 constexpr int block_threads(int logn) { return (LORA_SF12_R8 && logn == 12) ? 512 : 256; }
-constexpr unsigned kTicketQueues = 8, kTicketStride = 32;   // 8 counters, 128 bytes apart
+constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32;   // counters 128 bytes apart
 #ifndef LORA_ABL
 #define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax, 32 no LDS exchanges (SF12), 64 IQ from L2
 #endif
@@ -248,6 +248,10 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 // and is merged into the NEXT pass's twiddle table:
 //     twiddle(ps, rr, jm, m) = W_M^( m * (N/L_ps) * (F*jm + rr) ),  jm = j mod NS, L_ps = NS*r
 // What remains after the last pass is one factor per thread of magnitude 1, which |X|^2 drops.
+// A window of at most 64 threads lives inside one wave: its LDS exchanges need no workgroup barrier, only
+// program order (the DS operations of a wave execute in order; wave_barrier keeps the compiler from moving
+// them across), so the waves of such a workgroup never wait for each other.
+#define LORA_PASS_BARRIER() do { if constexpr (T > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier(); } while (0)
 template <int LOGN, int F, int PS, int NS>
 __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 *tile, const float2 *lds_tw,
                                          const int tw, const float2 *wb, const int rr LORA_STAMP_PARAMS) {
@@ -258,15 +262,15 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
   static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
   LORA_STAMP(2);                     // compute (butterflies, scatter) since the last stamp
   if constexpr (PS > 0) {
-    __syncthreads();                 // previous pass's scatter is visible
+    LORA_PASS_BARRIER();             // previous pass's scatter is visible
     LORA_STAMP(5);                   // barrier wait
 #pragma unroll
     for (int k = 0; k < R; k++) v[k] = tile[lds_pad(tw) + lds_pad(k * T)];
     LORA_STAMP(6);                   // LDS gather latency
-    if constexpr (!last) __syncthreads();   // everyone has read before the tile is overwritten
+    if constexpr (!last) LORA_PASS_BARRIER();   // everyone has read before the tile is overwritten
     LORA_STAMP(5);
   } else {
-    __syncthreads();                 // readers of the previous sub-transform / window are done
+    LORA_PASS_BARRIER();             // readers of the previous sub-transform / window are done
     LORA_STAMP(5);
   }
 #pragma unroll
@@ -527,23 +531,39 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
     }
   };
 
-  // ticket ring: group G(i) of iteration i; G(0) = blockIdx.x, G(i >= 1) = gridDim.x + ticket * queues + queue
-  // A ticket is published at the end of an iteration and may be read once a barrier has passed: at the
-  // prefetch point of the next iteration when a whole sub-transform lies before it (F = 2: two groups
+  // Work is drawn in groups.  Windows that span several waves (T > 64): a group is the WPB windows of the
+  // whole workgroup, G(0) = blockIdx.x, G(i >= 1) = gridDim.x + ticket * queues + queue; a ticket is
+  // published through the LDS ring at the end of an iteration and may be read once a barrier has passed: at
+  // the prefetch point of the next iteration when a whole sub-transform lies before it (F = 2: two groups
   // ahead, the smallest tail), else at the top of the iteration after the next (three groups ahead; also
   // used at F = 4, where the window arithmetic at the prefetch point would spill).
-  constexpr bool kLateRead = (F == 2);
+  // Windows inside one wave (T <= 64): every wave is a worker of its own, a group is the 64/T windows of
+  // one wave, and the ticket drawn by lane 0 one iteration earlier simply waits in a register.
+  constexpr bool kWaveLocal = (T <= 64);
+  constexpr int GW = kWaveLocal ? 64 / T : WPB;                    // windows per group
+  constexpr unsigned kWorkers = kWaveLocal ? kBlock / 64 : 1;       // workers per workgroup
+  constexpr unsigned kQueues = kWaveLocal ? kWaveTicketQueues : kTicketQueues;
+  constexpr bool kLateRead = (F == 2) && !kWaveLocal;
   constexpr int LOOK = kLateRead ? 2 : 3;
   unsigned *ring = reinterpret_cast<unsigned *>(red + 2 * (kBlock / 64));
-  const unsigned n_groups = (p.n_win + WPB - 1) / WPB;
-  const unsigned my_queue = blockIdx.x % kTicketQueues;
+  const unsigned n_groups = (p.n_win + GW - 1) / GW;
+  const unsigned n_workers = gridDim.x * kWorkers;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool drawer = kWaveLocal ? ((tid & 63) == 0) : (tid == 0);
+  const unsigned my_queue = kWaveLocal ? (blockIdx.x % kTicketQueues) * kWorkers + wave : blockIdx.x % kTicketQueues;
   unsigned *const my_ticket = p.ticket + my_queue * kTicketStride;
-  if (tid == 0) {
-    for (int s2 = 1; s2 < LOOK; s2++) ring[s2] = gridDim.x + atomicAdd(my_ticket, 1u) * kTicketQueues + my_queue;
+  const int wig = kWaveLocal ? (tid & 63) / T : wl;                 // window within the group
+  unsigned tk1 = 0;                                                 // wave-local: ticket of G(it + 1)
+  if constexpr (kWaveLocal) {
+    if (drawer) tk1 = atomicAdd(my_ticket, 1u);
+  } else {
+    if (drawer) {
+      for (int s2 = 1; s2 < LOOK; s2++) ring[s2] = n_workers + atomicAdd(my_ticket, 1u) * kQueues + my_queue;
+    }
   }
-  __syncthreads();
-  unsigned cur_g = blockIdx.x;
-  WinCtx cur = window_ctx<N>(p, cur_g * WPB + wl);
+  __syncthreads();                 // the LDS twiddle tables and the ring are visible
+  unsigned cur_g = kWaveLocal ? blockIdx.x * kWorkers + wave : blockIdx.x;
+  WinCtx cur = window_ctx<N>(p, cur_g * GW + wig);
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
   float2 cc[CONST_OFF ? R : 1];
   float cwin[CONST_OFF ? R : 1];
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
   for (unsigned it = 0; cur_g < n_groups; it++) {
     LORA_STAMP(0);
     unsigned tk = 0;
-    if (tid == 0) tk = atomicAdd(my_ticket, 1u);      // G(it + LOOK); lands while this group is processed
+    if (drawer) tk = atomicAdd(my_ticket, 1u);        // G(it + LOOK) (wave-local: G(it + 2)); lands while this group is processed
     // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
     float2 c[R];
     float w[R];
@@ -615,9 +635,12 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
     }
     unsigned nxt_g = 0;
     WinCtx nxt;
-    if constexpr (!kLateRead) {
+    if constexpr (kWaveLocal) {
+      nxt_g = n_workers + __builtin_amdgcn_readfirstlane(tk1) * kQueues + my_queue;   // drawn one iteration ago
+      nxt = window_ctx<N>(p, nxt_g * GW + wig);
+    } else if constexpr (!kLateRead) {
       nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);   // G(it + 1); uniform: scalar window arithmetic
-      nxt = window_ctx<N>(p, nxt_g * WPB + wl);
+      nxt = window_ctx<N>(p, nxt_g * GW + wig);
     }
 
     // ---- dechirp + window: x[k] <-> sample n = tw + k*T -----------------------------------
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
         asm volatile("" ::: "memory");
         if constexpr (kLateRead) {
           nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);
-          nxt = window_ctx<N>(p, nxt_g * WPB + wl);
+          nxt = window_ctx<N>(p, nxt_g * GW + wig);
         }
         const float2 *__restrict__ src = p.iq + ((LORA_ABL & 64) ? 0 : nxt.pos) + tw;   // ABL 64: every window reads window 0 (L2)
 #pragma unroll
@@ -692,7 +715,8 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
     } else {
       combine_store(cur, reduce_partial(best, par), bin0_nan, par);   // a window inside one wave is final already
     }
-    if (tid == 0) ring[it % LOOK] = gridDim.x + tk * kTicketQueues + my_queue;   // read LOOK - 1 iterations from now, behind barriers
+    if constexpr (kWaveLocal) tk1 = tk;
+    else if (drawer) ring[it % LOOK] = n_workers + tk * kQueues + my_queue;   // read LOOK - 1 iterations from now, behind barriers
     cur = nxt; cur_g = nxt_g;
     par ^= 1;
   }
