@@ -175,7 +175,10 @@ constexpr int plan_radix(int logn, int ps) {
 }
 constexpr int plan_ns(int logn, int ps) { int v = 1; for (int i = 0; i < ps; i++) v *= plan_radix(logn, i); return v; }
 
-constexpr int block_threads(int logn) { return (LORA_SF12_R8 && logn == 12) ? 512 : 256; }
+// Threads per workgroup.  SF11 at F >= 2: one window (two waves) per workgroup, so that a barrier never makes
+// the waves of one window wait for another window's (+5 %); at F = 1 its LDS table (16 KiB per workgroup)
+// would cost residency, so two windows share a 256-thread workgroup there.
+constexpr int block_threads(int logn, int f) { return (LORA_SF12_R8 && logn == 12) ? 512 : (logn == 11 && f >= 2) ? 128 : 256; }
 constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32;   // counters 128 bytes apart
 #ifndef LORA_ABL
 #define LORA_ABL 0   // timing-only ablations (wrong results): 1 no IQ loads, 2 no chirp/window loads, 4 no twiddle loads, 8 no wave reduction, 16 no argmax, 32 no LDS exchanges (SF12), 64 IQ from L2
@@ -442,8 +445,8 @@ __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned wi
 //   * otherwise they are requested first thing in iteration i, and the reduction + store of
 //     window i-1 runs while they are in flight.
 template <int LOGN, int F, bool CONST_OFF>
-__global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_kernel(const KParams p) {
-  constexpr int kBlock = block_threads(LOGN);
+__global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN)) void demod_kernel(const KParams p) {
+  constexpr int kBlock = block_threads(LOGN, F);
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R, WPB = kBlock / T;
   constexpr int PADN = N + N / 16;
   static_assert(T >= 1 && T <= kBlock && WPB >= 1, "geometry");
@@ -734,12 +737,12 @@ __global__ __launch_bounds__(block_threads(LOGN), min_waves(LOGN)) void demod_ke
 
 template <int LOGN, int F>
 constexpr size_t demod_lds_bytes() {
-  constexpr int kBlock = block_threads(LOGN);
+  constexpr int kBlock = block_threads(LOGN, F);
   constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
   return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
          2 * (kBlock / 64) * sizeof(Best) + 16 /* ticket ring */;
 }
-template <int LOGN>
-constexpr int demod_wpb() { return block_threads(LOGN) / ((1 << LOGN) / plan_points(LOGN)); }
+template <int LOGN, int F>
+constexpr int demod_wpb() { return block_threads(LOGN, F) / ((1 << LOGN) / plan_points(LOGN)); }
 
 }  // namespace lora_hip
