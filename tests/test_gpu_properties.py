@@ -191,3 +191,26 @@ def test_back_to_back_async_launches_on_one_stream(sf, f, g):
         assert np.array_equal(oi.cpu().numpy().view(np.uint16), ref_idx[:c]), c
         assert np.array_equal(ov.cpu().numpy().view(np.uint32), ref_val[:c].view(np.uint32)), c
     h.close()
+
+
+def test_handles_and_blocks_release_their_memory(g):
+    """create/destroy cycles (with staging, pinned result block and ticket counters in use) leave the device
+    memory where it was."""
+    import torch
+    cap, _, _ = cases.make_capture(9, [12], seed=9)
+    blk = g.demod(9, False, cases.BETA, 2); blk.work(cap); blk.close()          # warm up allocator pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(200):
+        blk = g.demod(9, False, cases.BETA, 2)
+        assert len(blk.work(cap)) == 1
+        if k % 2:
+            blk.reset(); blk.work(cap[:5000])
+        blk.close()
+        h = g.HipDemod(7 + k % 6, (1, 2, 4)[k % 3], cases.BETA)
+        n = 1 << (7 + k % 6)
+        h.batch_strided(cap, 0, n, min(8, len(cap) // n))
+        h.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 200 create/destroy cycles"
