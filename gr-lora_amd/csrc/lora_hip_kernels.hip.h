@@ -50,13 +50,6 @@ __device__ __forceinline__ float magsq(float2 a) { return __builtin_fmaf(a.x, a.
 // a * (-j)
 __device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }
 
-// volk_32fc_x2_multiply_32fc, generic/SSE3 arithmetic: every product and sum rounded once, no
-// FMA contraction (demod_impl.cc:179/183/310)
-__device__ __forceinline__ float2 cmul_volk(float2 a, float2 b) {
-  return make_float2(__fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)),
-                     __fadd_rn(__fmul_rn(a.x, b.y), __fmul_rn(a.y, b.x)));
-}
-
 // 64th roots of unity, W_64^k = exp(-2 pi i k / 64), as compile-time constants: the pass-0 input
 // constants of the zero-padding twist, W_(F*R)^(rr*m), are all among them (F*R <= 64), so they
 // cost no load at all.  Values are cos(2 pi k / 64) evaluated in double and rounded once.
@@ -568,16 +561,16 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN)) void demod
   unsigned cur_g = kWaveLocal ? blockIdx.x * kWorkers + wave : blockIdx.x;
   WinCtx cur = window_ctx<N>(p, cur_g * GW + wig);
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
+  // (taps = chirp x Kaiser window, multiplied once: see the dechirp below)
   float2 cc[CONST_OFF ? R : 1];
-  float cwin[CONST_OFF ? R : 1];
   if constexpr (CONST_OFF) {
     const float2 *__restrict__ chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
     const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-      cc[k] = chirp[k * T];
-      const float wk = wsrc[k * T];
-      cwin[k] = (p.kind == 0) ? wk : 1.0f;
+      const float2 ck = chirp[k * T];
+      const float wk = (p.kind == 0) ? wsrc[k * T] : 1.0f;     // the SFD path has no window (:310)
+      cc[k] = make_float2(ck.x * wk, ck.y * wk);
     }
   }
   // last pass with a table too big for LDS: the base twiddle W_M^((N/L)*(F*jm + rr)) of each of this
@@ -618,21 +611,20 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN)) void demod
     if (drawer) tk = atomicAdd(my_ticket, 1u);        // G(it + LOOK) (wave-local: G(it + 2)); lands while this group is processed
     // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
     float2 c[R];
-    float w[R];
     if constexpr (CONST_OFF) {
 #pragma unroll
-      for (int k = 0; k < R; k++) { c[k] = cc[k]; w[k] = cwin[k]; }
+      for (int k = 0; k < R; k++) c[k] = cc[k];
     } else {
       const float2 *__restrict__ chirp = (cur.kind == 0 ? p.down : p.up) + cur.off + tw;
       const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
       for (int k = 0; k < R; k++) {
 #if LORA_ABL & 2
-        c[k] = make_float2(0.5f, tw * 0.001f); w[k] = 0.3f;
+        c[k] = make_float2(0.5f, tw * 0.001f);
 #else
-        c[k] = chirp[k * T];
-        const float wk = wsrc[k * T];
-        w[k] = (cur.kind == 0) ? wk : 1.0f;            // t*1.0f == t bit for bit (the SFD path has no window)
+        const float2 ck = chirp[k * T];
+        const float wk = (cur.kind == 0) ? wsrc[k * T] : 1.0f;   // the SFD path has no window (:310)
+        c[k] = make_float2(ck.x * wk, ck.y * wk);                // same products as the CONST_OFF taps: both paths agree bit for bit
 #endif
       }
     }
@@ -650,8 +642,11 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN)) void demod
     float2 x[R];
 #pragma unroll
     for (int k = 0; k < R; k++) {
-      const float2 t = cmul_volk(nx[k], c[k]);                             // :179/:183/:310
-      x[k] = make_float2(__fmul_rn(t.x, w[k]), __fmul_rn(t.y, w[k]));      // :192
+      // :179/:183/:192/:310 as one complex multiply by (chirp x window): x*(c*w) instead of the reference's
+      // (x*c)*w and FMA instead of VOLK's separately rounded products -- 4 VALU per sample instead of 8 and 16
+      // fewer live registers; the FFT input differs from the reference's by at most ~1.5 ulp, three orders of
+      // magnitude inside the 1e-4 bar (measured agreement with the oracle: profiles/r01_v13_accuracy.txt)
+      x[k] = cmul(nx[k], c[k]);
     }
     LORA_STAMP(1);    // operands landed + dechirp
 

@@ -1,6 +1,6 @@
 """Randomised differential test of the whole block against the oracle (generator: tools/fuzz_l2.py).
 400 seeded cases here; a 150 s run (8631 cases, 824 k calls, 13 959 PDUs) is recorded in
-profiles/r01_v11_fuzz.txt."""
+profiles/r01_fuzz.txt."""
 import os
 import sys
 
