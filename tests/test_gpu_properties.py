@@ -214,3 +214,26 @@ def test_handles_and_blocks_release_their_memory(g):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 200 create/destroy cycles"
+
+
+@pytest.mark.parametrize("sf,f", [(6, 2), (8, 1), (9, 4), (11, 2), (12, 2)])
+def test_every_window_exactly_once_whatever_the_grid(sf, f, g, monkeypatch):
+    """The persistent kernel hands out window groups by ticket: the result must not depend on how many
+    workgroups are resident (LORA_HIP_BLOCKS_PER_CU = 1, 2, default) nor on the number of windows (from fewer
+    than one group to thousands, not a multiple of the group size)."""
+    n = 1 << sf
+    rng = np.random.default_rng(100 + sf)
+    n_win = 3000 if sf <= 10 else 1100
+    iq = (rng.standard_normal(n_win * n) + 1j * rng.standard_normal(n_win * n)).astype(np.complex64)
+    h = g.HipDemod(sf, f, cases.BETA)
+    ref_idx, ref_val = h.batch_strided(iq, 0, n, n_win)
+    h.close()
+    for bpc in ("1", "2"):
+        monkeypatch.setenv("LORA_HIP_BLOCKS_PER_CU", bpc)
+        h = g.HipDemod(sf, f, cases.BETA)
+        for count in (1, 2, 5, 63, 64, 65, 257, 1023, n_win - 1, n_win):
+            idx, val = h.batch_strided(iq, 0, n, count)
+            assert np.array_equal(idx, ref_idx[:count]), (bpc, count)
+            assert np.array_equal(val.view(np.uint32), ref_val[:count].view(np.uint32)), (bpc, count)
+        h.close()
+    monkeypatch.delenv("LORA_HIP_BLOCKS_PER_CU")
