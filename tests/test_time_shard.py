@@ -181,3 +181,40 @@ def test_gpu_preload_argument_checks():
         blk.preload(5, np.zeros(4, np.uint16), np.zeros(4, np.float32))      # not on the N/16 lattice
     blk.preload(16, np.zeros(0, np.uint16), np.zeros(0, np.float32))         # empty: accepted
     blk.close()
+
+
+# ---- property-based: segmentation/merge for arbitrary sizes, with a position-only fake evaluator ----------
+
+def test_merge_matches_direct_evaluation_for_random_sizes():
+    from hypothesis import given, settings, strategies as st
+
+    class FakeSweep:
+        """(idx, val) depend only on the framed-stream position of a window: sum of its first two samples."""
+        def __init__(self, n):
+            self.n = n
+
+        def __call__(self, seg, pos0, count):
+            p = pos0 + self.n * np.arange(count)
+            v = (seg[p].real + 2 * seg[p + self.n - 1].real).astype(np.float32)
+            return (v.astype(np.int64) % 65536).astype(np.uint16), v
+
+    @settings(max_examples=60, deadline=None)
+    @given(sf=st.integers(6, 9), n_samples=st.integers(0, 6000), world=st.integers(1, 9))
+    def check(sf, n_samples, world):
+        n = 1 << sf
+        cap = (np.arange(1, n_samples + 1) % 251).astype(np.complex64)
+        sweep = FakeSweep(n)
+        parts = [shard.sweep_segment(sweep, cap, sf, q0, q1) for q0, q1 in shard.lattice_partition(n_samples, sf, world)]
+        runs = shard.merge_sweeps(parts, sf)
+        framed = shard.framed_slice(cap, sf, 0, 3 * n - 1 + n_samples)
+        seen = 0
+        for start, idx, val in runs:
+            assert start % (n // 16) == 0 and start < n
+            ridx, rval = sweep(framed, start, len(idx))
+            assert np.array_equal(idx, ridx) and np.array_equal(val, rval)
+            seen += len(idx)
+        # every lattice start whose window fits in the framed stream is covered exactly once
+        total = (len(framed) - n) // (n // 16) + 1 if len(framed) >= n else 0
+        assert seen == total
+
+    check()
