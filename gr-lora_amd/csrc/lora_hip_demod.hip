@@ -64,7 +64,7 @@ template <int LOGN, int F>
 Variant make_variant(const char *name) {
   return Variant{&lora_hip::demod_kernel<LOGN, F, false>, &lora_hip::demod_kernel<LOGN, F, true>,
                  lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN, F>(), lora_hip::block_threads(LOGN, F),
-                 lora_hip::min_waves(LOGN) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name};
+                 lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name};
 }
 
 #define LORA_VARIANTS_SF(SF) \
