@@ -13,7 +13,7 @@
 //    N points of x[n]*exp(-2 pi i r n / M), r < F (decimation in frequency by F), bin F*k + r.
 //  * each N-point DFT is a Stockham autosort FFT with register-resident radix-16/8/4
 //    butterflies; passes exchange data through a padded LDS tile (<= 34 KiB per workgroup).
-//  * the spectrum is reduced to (max, argmax) in registers, then with wave64 shuffles and one
+//  * the spectrum is reduced to (max, argmax) in registers, then with wave64 DPP steps and one
 //    small LDS step; the IQ is read from HBM exactly once with coalesced 8-byte lane loads.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference
 #endif
 
-  // Reduction over the T threads of a window.  Part 1 (end of window i): wave64 shuffles, then one
+  // Reduction over the T threads of a window.  Part 1 (end of window i): wave64 DPP steps, then one
   // partial per wave into red[i & 1][wave] -- no barrier.  Part 2 (inside window i+1, after its
   // first pass barriers): thread 0 of the window combines the partials and stores (idx, max).
   // The two red[] halves alternate, so a half is rewritten two windows later, behind barriers.
