@@ -45,8 +45,22 @@ def single_capture_latency(sf=12, f=2, n_samples=1_250_000, reps=50):
     for _ in range(reps):
         h.batch_strided(iq, 0, n, count)                                  # results copied to host memory
     host = (time.perf_counter() - t0) / reps
+    # the same call recorded 64 times into a HIP graph (LORA_HIP_ASYNC on the capture stream) and replayed
+    st = torch.cuda.Stream(); h.set_stream(st.cuda_stream)
+    h.batch_strided(iq, 0, n, count, out_idx=oi, out_val=ov, async_=True); st.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        for _ in range(64):
+            h.batch_strided(iq, 0, n, count, out_idx=oi, out_val=ov, async_=True)
+    graph.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    gr = (time.perf_counter() - t0) / 640
     print(f"single capture SF{sf} F{f}: {count} windows of a {n_samples}-sample capture in HBM: {dev*1e6:.0f} us per call "
-          f"(results in HBM), {host*1e6:.0f} us with results in host memory", flush=True)
+          f"(results in HBM), {host*1e6:.0f} us with results in host memory, {gr*1e6:.1f} us per call inside a replayed "
+          f"HIP graph of 64 calls", flush=True)
     h.close()
 
 def e2e(sf, f, seconds_of_capture=40):
