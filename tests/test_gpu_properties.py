@@ -273,3 +273,30 @@ def test_async_calls_can_be_captured_in_a_hip_graph(g):
             assert np.array_equal(oi.cpu().numpy().view(np.uint16), ridx)
             assert np.array_equal(ov.cpu().numpy().view(np.uint32), rval.view(np.uint32))
     h.close()
+
+
+@pytest.mark.parametrize("sf", [7, 9, 10, 12])
+def test_measured_agreement_is_far_inside_the_bar(sf, g):
+    """The bar is 1e-4 relative on max|X|^2 and exact indices above a 1e-4 margin; what the kernels deliver is
+    about 1e-6 and exact indices down to margins of 1e-6 (tools/accuracy.py).  Guard that headroom with 1e-5."""
+    n = 1 << sf
+    rng = np.random.default_rng(sf)
+    n_win = 256 if sf <= 10 else 96
+    noise = (rng.standard_normal(n_win * n) + 1j * rng.standard_normal(n_win * n)).astype(np.complex64)
+    chirps = oracle.modulate(sf, oracle.random_symbols(sf, n_win // 2, 5 + sf), cases.SYNC_WORD)
+    iq = noise.copy()
+    k = min(len(chirps), len(iq) // 2)
+    iq[:k] = chirps[:k] + 0.3 * noise[:k]
+    pos = np.sort(rng.integers(0, len(iq) - n, n_win)).astype(np.uint64)
+    off = (rng.integers(0, 16, n_win) * (n // 16)).astype(np.uint16)
+    kind = rng.integers(0, 2, n_win).astype(np.uint8)
+    for f in (1, 2, 4):
+        d = oracle.Demod(sf, False, cases.BETA, f)
+        ridx, rval, margin = d.window_argmax(iq, pos, off, kind)
+        h = g.HipDemod(sf, f, cases.BETA)
+        idx, val = h.batch(iq, g.make_desc(pos, off, kind))
+        h.close()
+        nz = rval > 0
+        assert np.max(np.abs(val[nz] - rval[nz]) / rval[nz]) <= 1e-5
+        decided = margin > 1e-5
+        assert np.array_equal(idx[decided], ridx[decided])
