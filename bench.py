@@ -82,8 +82,8 @@ def cpu_baseline(capture, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)      # clocks and TLBs settle within ~50 launches (+4 % over warmup 5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
