@@ -128,6 +128,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # what a plain device copy of the same buffer reaches on this GPU (read + write bytes per second):
+    # the practical ceiling beside the 8 TB/s specification.  Set-up work, done on every rank
+    # before the warm-up steps, outside the timed region.
+    raw = iq.view(torch.float32)
+    dst = torch.empty_like(raw)
+    with torch.cuda.stream(stream):
+        dst.copy_(raw)
+        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(20):
+            dst.copy_(raw)
+        c1.record(stream)
+    stream.synchronize()
+    copy_gbs = 2 * raw.numel() * 4 * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del dst, raw
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -140,23 +156,6 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
-
-    # what a plain device copy of the same buffer reaches on this GPU (read + write bytes per second):
-    # the practical ceiling beside the 8 TB/s specification; outside the timed region
-    copy_gbs = None
-    if rank == 0:
-        raw = iq.view(torch.float32)
-        dst = torch.empty_like(raw)
-        with torch.cuda.stream(stream):
-            dst.copy_(raw)
-            c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-            c0.record(stream)
-            for _ in range(5):
-                dst.copy_(raw)
-            c1.record(stream)
-        stream.synchronize()
-        copy_gbs = 2 * raw.numel() * 4 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        del dst
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)

@@ -130,6 +130,7 @@ class HipDemod:
         self.sf, self.fft_factor, self.N = sf, fft_factor, 1 << sf
         self._staged_n = 0
         self._h = C.c_void_p()
+        self._destroy = lib().lora_hip_demod_destroy      # bound now: module globals are gone at interpreter exit
         args = [None, None, None]
         if window is not None:
             self._tabs = (np.ascontiguousarray(window, np.float32), np.ascontiguousarray(upchirp, np.complex64),
@@ -142,7 +143,7 @@ class HipDemod:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().lora_hip_demod_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -43,6 +43,24 @@ int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
 }
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
 
+// Makes the handle's device current for the scope of one entry point and puts the caller's device back
+// afterwards: the library runs inside processes (GNU Radio flowgraphs with several blocks, torch) that keep
+// their own idea of the current device per thread.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err != hipSuccess) { prev = -1; return; }
+    if (prev == device) { prev = -1; return; }       // nothing to restore
+    err = hipSetDevice(device);
+    if (err != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 template <typename T>
 int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
   if (want <= *cap) return LORA_HIP_OK;
@@ -249,11 +267,10 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
       NS = L;
     }
   }
-  int rc = LORA_HIP_OK;
   auto fail = [&](int code) { lora_hip_demod_destroy(h); return code; };
-  hipError_t e;
-  if ((e = hipSetDevice(device)) != hipSuccess) { return fail(LORA_HIP_EHIP); }
-  if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail(LORA_HIP_EHIP);
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(LORA_HIP_EHIP);
   h->stream = h->own_stream;
   if (hipMalloc((void **)&h->d_up, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_down, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
@@ -269,20 +286,19 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LORA_HIP_EHIP);
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  // kernels with more than 64 KiB of dynamic LDS need the opt-in
+  // kernels with more dynamic LDS than the runtime's default limit need the opt-in
   if (v.lds > 48 * 1024) {
     if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
       return fail(LORA_HIP_EHIP);
   }
-  (void)rc;
   *out = h;
   return LORA_HIP_OK;
 }
 
 void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
   (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
@@ -298,7 +314,8 @@ int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream) {
 
 int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a, const lora_c32 *b, size_t n_b) {
   if (!h || (!a && n_a) || (!b && n_b)) return LORA_HIP_EINVAL;
-  HIP_TRY(h, hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
   h->staged_n = 0;
   const size_t n = n_a + n_b;
   int rc = grow(h, &h->d_iq, &h->cap_iq, n ? n : 1);
@@ -329,7 +346,8 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   if ((flags & LORA_HIP_ASYNC) && ((!iq_dev && !iq_staged) || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
   if (n_win == 0) return LORA_HIP_OK;
   if (n_samples < h->n) return LORA_HIP_EINVAL;      // the kernel redirects bad windows to sample 0
-  HIP_TRY(h, hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
   int rc;
   // inputs
   if (iq_dev) p.iq = reinterpret_cast<const float2 *>(iq);

@@ -31,6 +31,7 @@ class demod:
         self.spreading_factor, self.low_data_rate = int(spreading_factor), bool(low_data_rate)
         self.beta, self.fft_factor = float(beta), int(fft_factor)
         self._h = C.c_void_p()
+        self._destroy = capi.lib().lora_demod_core_destroy    # bound now: module globals are gone at interpreter exit
         rc = capi.lib().lora_demod_core_create(C.byref(self._h), device, self.spreading_factor,
                                                int(self.low_data_rate), self.beta, self.fft_factor)
         if rc:
@@ -47,7 +48,7 @@ class demod:
 
     def close(self):
         if getattr(self, "_h", None):
-            capi.lib().lora_demod_core_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
