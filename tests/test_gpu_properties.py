@@ -300,3 +300,52 @@ def test_measured_agreement_is_far_inside_the_bar(sf, g):
         assert np.max(np.abs(val[nz] - rval[nz]) / rval[nz]) <= 1e-5
         decided = margin > 1e-5
         assert np.array_equal(idx[decided], ridx[decided])
+
+
+def test_handles_are_reentrant_across_threads(g):
+    """several demod instances run on different scheduler threads at once, so the C ABI is
+    re-entrant per handle.  Four threads, one handle each (different SF/F), hammer one GPU concurrently;
+    every result must equal the one the same handle configuration produced alone."""
+    import threading
+    cfgs = [(7, 2), (9, 1), (10, 4), (12, 2)]
+    rng = np.random.default_rng(77)
+    work, alone = [], []
+    for sf, f in cfgs:
+        n = 1 << sf
+        iq = ((rng.standard_normal(64 * n) + 1j * rng.standard_normal(64 * n)) * 0.05).astype(np.complex64)
+        work.append(iq)
+        h = g.HipDemod(sf, f, cases.BETA)
+        alone.append(h.batch_strided(iq, 0, n, 64, 0, 0, g.capi.WIN_UP))
+        h.close()
+    errors = []
+
+    def worker(k):
+        try:
+            sf, f = cfgs[k]
+            h = g.HipDemod(sf, f, cases.BETA)
+            for _ in range(50):
+                idx, val = h.batch_strided(work[k], 0, 1 << sf, 64, 0, 0, g.capi.WIN_UP)
+                if not (np.array_equal(idx, alone[k][0]) and np.array_equal(val, alone[k][1])):
+                    errors.append((cfgs[k], "result differs under concurrency"))
+                    break
+            h.close()
+        except Exception as e:      # surfaced below: an exception in a thread must fail the test
+            errors.append((cfgs[k], repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(cfgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_calls_leave_the_callers_current_device_alone(g):
+    """The library makes its handle's device current only for the duration of a call."""
+    import torch
+    before = torch.cuda.current_device()
+    h = g.HipDemod(8, 2, cases.BETA, device=0)
+    iq = np.zeros(4 * 256, np.complex64)
+    h.batch_strided(iq, 0, 256, 4, 0, 0, g.capi.WIN_UP)
+    h.close()
+    assert torch.cuda.current_device() == before
