@@ -20,6 +20,8 @@ struct lora_hip_demod {
   float2 *d_up = nullptr, *d_down = nullptr;
   float *d_win = nullptr;
   float2 *d_tw = nullptr;       // the pass tables
+  float2 *d_twist = nullptr;    // any-factor kernels: W_M^e, e < M
+  bool anyf = false;            // fft_factor outside {1, 2, 4}: run-time number of sub-transforms
   size_t tw_off[4] = {0, 0, 0, 0};
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
@@ -85,12 +87,20 @@ Variant make_variant(const char *name) {
                  lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name};
 }
 
+template <int LOGN>
+Variant make_variant_anyf(const char *name) {
+  // no register-resident-taps variant: x stays live across the run-time loop and the registers are needed there
+  return Variant{&lora_hip::demod_kernel<LOGN, 1, false, true>, &lora_hip::demod_kernel<LOGN, 1, false, true>,
+                 lora_hip::demod_lds_bytes<LOGN, 1>(), lora_hip::demod_wpb<LOGN, 1>(), lora_hip::block_threads(LOGN, 1),
+                 lora_hip::min_waves(LOGN, 1) * 4 / (lora_hip::block_threads(LOGN, 1) / 64), name};
+}
+
 #define LORA_VARIANTS_SF(SF) \
   case SF: \
     if (f == 1) { *v = make_variant<SF, 1>("demod_kernel<" #SF ",1>"); return true; } \
     if (f == 2) { *v = make_variant<SF, 2>("demod_kernel<" #SF ",2>"); return true; } \
     if (f == 4) { *v = make_variant<SF, 4>("demod_kernel<" #SF ",4>"); return true; } \
-    return false;
+    *v = make_variant_anyf<SF>("demod_kernel<" #SF ",any>"); return true;
 
 bool pick_variant(unsigned sf, unsigned f, Variant *v) {
   switch (sf) {
@@ -119,6 +129,7 @@ int launch(lora_hip_demod *h, KParams &p) {
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
     p.ticket = h->d_ticket;
   }
+  p.twist = h->d_twist; p.fr = h->fft_factor;
   // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
   const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
   hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), v.lds, h->stream, p);
@@ -169,7 +180,7 @@ const char *lora_hip_strerror(int code) {
   switch (code) {
     case LORA_HIP_OK: return "ok";
     case LORA_HIP_EINVAL: return "invalid argument";
-    case LORA_HIP_EUNSUPPORTED: return "unsupported fft_factor (supported: 1, 2, 4)";
+    case LORA_HIP_EUNSUPPORTED: return "unsupported fft_factor (2^sf * fft_factor must be below 65536, the reference's 16-bit FFT size)";
     case LORA_HIP_ENOMEM: return "out of memory";
     case LORA_HIP_EHIP: return "HIP runtime error";
     case LORA_HIP_ENODEVICE: return "no usable GPU device";
@@ -212,7 +223,8 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (!out) return LORA_HIP_EINVAL;
   *out = nullptr;
   if (sf < 6 || sf > 12 || fft_factor == 0) return LORA_HIP_EINVAL;   // asserts at demod_impl.cc:70-72
-  if (fft_factor != 1 && fft_factor != 2 && fft_factor != 4) return LORA_HIP_EUNSUPPORTED;
+  // d_fft_size is an unsigned short (demod_impl.h:52): a product of 65536 or more wraps in the reference
+  if (((unsigned long long)fft_factor << sf) > 65535ull) return LORA_HIP_EUNSUPPORTED;
   const bool all_null = !window_n && !up_2n && !down_2n;
   if (!all_null && (!window_n || !up_2n || !down_2n)) return LORA_HIP_EINVAL;
   int ndev = 0;
@@ -223,6 +235,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (!h) return LORA_HIP_ENOMEM;
   h->device = device; h->sf = sf; h->fft_factor = fft_factor;
   h->n = 1u << sf; h->m = h->n * fft_factor;
+  h->anyf = (fft_factor != 1 && fft_factor != 2 && fft_factor != 4);
   Variant v;
   pick_variant(sf, fft_factor, &v);
   h->kernel_name = v.name;
@@ -244,12 +257,14 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   //   twp[ps][rr][m-1][jm]  = W_M^(m*(N/L_ps)*(F*jm + rr))         merged pass twiddles, ps >= 1
   //   (a last pass too big for LDS stores m = 1 only; the kernel keeps it in registers)
   std::vector<lora_c32> tw;
+  // the any-factor kernel runs N-point transforms (F = 1 tables) behind a full input twist
+  const unsigned F = h->anyf ? 1u : fft_factor;
+  const size_t mt = n * F;
   auto wm = [&](unsigned long long e) {
-    const double a = -2.0 * M_PI * (double)(e % m) / (double)m;
+    const double a = -2.0 * M_PI * (double)(e % mt) / (double)mt;
     return lora_c32{(float)std::cos(a), (float)std::sin(a)};
   };
   const int NP = lora_hip::plan_passes((int)sf);
-  const unsigned F = fft_factor;
   {
     unsigned long long NS = lora_hip::plan_radix((int)sf, 0);
     for (int ps = 1; ps < NP; ps++) {
@@ -281,6 +296,15 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (h->anyf) {
+    std::vector<lora_c32> twist(m);
+    for (size_t e = 0; e < m; e++) {
+      const double a = -2.0 * M_PI * (double)e / (double)m;
+      twist[e] = lora_c32{(float)std::cos(a), (float)std::sin(a)};
+    }
+    if (hipMalloc((void **)&h->d_twist, m * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+    if (hipMemcpy(h->d_twist, twist.data(), m * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LORA_HIP_EHIP);
@@ -300,7 +324,7 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
-  (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw);
+  (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw); (void)hipFree(h->d_twist);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;

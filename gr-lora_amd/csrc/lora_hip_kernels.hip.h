@@ -34,6 +34,8 @@ struct KParams {
   unsigned short *out_idx;
   float *out_val;
   unsigned *ticket;             // kTicketQueues counters, 128 B apart, zeroed before the launch
+  const float2 *twist;          // any-factor kernels only: W_M^e, e < M = N*fr
+  unsigned fr;                  // any-factor kernels only: the run-time fft_factor
   unsigned long long *dbg;      // diagnostic builds only (LORA_STAMPS): per-workgroup phase cycle sums
 };
 
@@ -441,8 +443,14 @@ __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned wi
 //     Kaiser taps of a thread are the same for every window, loaded once, kept in VGPRs;
 //   * otherwise they are requested first thing in iteration i, and the reduction + store of
 //     window i-1 runs while they are in flight.
-template <int LOGN, int F, bool CONST_OFF>
+//
+// ANYF (fft_factor other than 1, 2, 4; the reference takes any): the same kernel with the N-point geometry and
+// tables of F = 1 and a run-time number of sub-transforms p.fr.  Sub-transform rr gets the whole twist
+// x[n] * W_M^(rr*n) at its input, one complex multiply per sample by a table value that L2 keeps
+// (rr*n < M, so the table index needs no reduction), and then runs the plain N-point transform.
+template <int LOGN, int F, bool CONST_OFF, bool ANYF = false>
 __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void demod_kernel(const KParams p) {
+  static_assert(!ANYF || F == 1, "the any-factor kernel is built on the F = 1 geometry");
   constexpr int kBlock = block_threads(LOGN, F);
   constexpr int N = 1 << LOGN, R = plan_points(LOGN), T = N / R, WPB = kBlock / T;
   constexpr int PADN = N + N / 16;
@@ -603,7 +611,8 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   // The store of window i is deferred into window i + 1 when the window spans several waves (the partials
   // meet behind the next window's barriers) and, measured, whenever F > 1; at F = 1 with a window inside one
   // wave storing at once frees the registers of the deferred state (SF7/SF8: +28 % / +41 %).
-  constexpr bool kDeferStore = (T > 64) || (F > 1);
+  constexpr bool kDeferStore = (T > 64) || (F > 1) || ANYF;
+  const int FR = ANYF ? (int)p.fr : F;            // sub-transforms per window
   WinCtx prev = cur;
   Best prev_best = {-1.0f, 0};
   bool prev_nan = false, have_prev = false;
@@ -656,20 +665,26 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 
     Best best = {-1.0f, 0};
     bool bin0_nan = false;
-#pragma unroll
-    for (int rr = 0; rr < F; rr++) {
+#pragma unroll ANYF ? 1 : F
+    for (int rr = 0; rr < FR; rr++) {
       float2 v[R];
       // decimation in frequency by F: bins F*k + rr come from x[n] * exp(-2 pi i rr n / M)
       if (rr == 0) {
 #pragma unroll
         for (int k = 0; k < R; k++) v[k] = x[k];
+      } else if constexpr (ANYF) {
+        const float2 *__restrict__ tws = p.twist + rr * tw;         // W_M^(rr*(tw + k*T))
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = cmul(x[k], tws[k * (rr * T)]);
       } else {
         static_assert(64 % (F * R) == 0, "pass-0 twist constants are 64th roots of unity");
 #pragma unroll
         for (int k = 0; k < R; k++) v[k] = mul_w64(x[k], rr * k * (64 / (F * R)));   // W_M^(rr*k*T)
       }
-      if (rr == F - 1) {
+      if (!ANYF && rr == F - 1) {
         // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
+        // (any-factor kernels: the compiler cannot see that in a run-time loop, x and nx would both stay
+        // live and spill; they load after the loop instead)
         asm volatile("" ::: "memory");
         if constexpr (kLateRead) {
           nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);
@@ -685,8 +700,9 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #endif
         }
       }
-      if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[rr], rr LORA_STAMP_ARGS);
-      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? rr * NBL : 0), rr LORA_STAMP_ARGS);
+      const int trr = ANYF ? 0 : rr;                // row of the twiddle tables: the any-factor twist is already in v
+      if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[trr], trr LORA_STAMP_ARGS);
+      else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? trr * NBL : 0), trr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
       if constexpr (kDeferStore) {
         if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
@@ -704,12 +720,17 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #if LORA_ABL & 16
         b.v += mag;
 #else
-        if (mag > b.v) { b.v = mag; b.i = F * kout + rr; }
+        if (mag > b.v) { b.v = mag; b.i = FR * kout + rr; }
 #endif
       }
       best = (rr == 0) ? b : better(best, b);
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
       asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
+    }
+    if constexpr (ANYF) {
+      const float2 *__restrict__ src = p.iq + nxt.pos + tw;
+#pragma unroll
+      for (int k = 0; k < R; k++) nx[k] = src[k * T];
     }
     if constexpr (kDeferStore) {
       prev_best = reduce_partial(best, par);

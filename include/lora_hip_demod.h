@@ -33,7 +33,7 @@ typedef struct lora_hip_demod lora_hip_demod_t;
 enum {
   LORA_HIP_OK = 0,
   LORA_HIP_EINVAL = -1,        /* bad argument (NULL, sf outside 6..12, window past the buffer) */
-  LORA_HIP_EUNSUPPORTED = -2,  /* fft_factor not in {1,2,4} */
+  LORA_HIP_EUNSUPPORTED = -2,  /* 2^sf * fft_factor >= 65536: wraps the reference's unsigned short d_fft_size */
   LORA_HIP_ENOMEM = -3,        /* host or device allocation failed */
   LORA_HIP_EHIP = -4,          /* a HIP runtime call failed; see lora_hip_last_hip_error() */
   LORA_HIP_ENODEVICE = -5      /* no usable gfx950 device / device index out of range */
@@ -82,6 +82,10 @@ LORA_HIP_API int lora_hip_make_kaiser(unsigned ntaps, double beta, float *window
  * window (:85) and chirp tables (:92-101) are copied to HBM of `device`; the caller keeps
  * ownership of the three host arrays.  Passing NULL for all three makes the library build them
  * with the functions above from (sf, beta).  One HIP stream is created per handle.
+ * fft_factor: any value >= 1 with 2^sf * fft_factor < 65536, as in the reference (its FFT size is
+ * fft_factor * 2^sf handed to FFTW, demod_impl.cc:80-81, kept in an unsigned short).  1, 2 and 4 -- the
+ * values the reference's flowgraphs use -- run specialised kernels; every other value runs a generic one
+ * (run-time number of N-point sub-transforms), same results contract, lower throughput.
  */
 LORA_HIP_API int lora_hip_demod_create(lora_hip_demod_t **h, int device, unsigned sf,
                                        unsigned fft_factor, float beta, const float *window_n,

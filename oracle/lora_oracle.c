@@ -39,6 +39,10 @@ typedef struct { double re, im; } lo_c64;
  * (call sites demod_impl.cc:81,201-203,317-319).  FFTW itself is not available; this is a
  * textbook iterative radix-2 decimation-in-time transform in single precision with twiddles
  * rounded from double, and the same transform in double precision for margin analysis.
+ * A size that is not a power of two (fft_factor 3, 5, 6 ...: the reference hands any M to FFTW)
+ * goes through a textbook recursive mixed-radix decimation-in-time transform instead: split by
+ * the smallest prime factor p, transform the p decimated sequences, combine with a direct
+ * p-point DFT.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   unsigned m, logm;
@@ -47,6 +51,9 @@ typedef struct {
   lo_c64 *twd;       /* same in double */
   lo_c32 *in, *out;  /* the plan's buffers, like gr::fft's get_inbuf()/get_outbuf() */
   lo_c64 *dwork;
+  int mixed;         /* m is not a power of two */
+  lo_c32 *mtw;       /* mixed radix: mtw[k] = exp(-j 2 pi k / M), k < M */
+  lo_c64 *mtwd, *din;
 } lo_fft;
 
 static lo_fft *fft_create(unsigned m)
@@ -71,19 +78,66 @@ static lo_fft *fft_create(unsigned m)
   p->in = (lo_c32 *)aligned_alloc(64, sizeof(lo_c32) * m);
   p->out = (lo_c32 *)aligned_alloc(64, sizeof(lo_c32) * m);
   p->dwork = (lo_c64 *)malloc(sizeof(lo_c64) * m);
+  p->mixed = (m & (m - 1)) != 0;
+  if (p->mixed) {
+    p->mtw = (lo_c32 *)malloc(sizeof(lo_c32) * m);
+    p->mtwd = (lo_c64 *)malloc(sizeof(lo_c64) * m);
+    p->din = (lo_c64 *)malloc(sizeof(lo_c64) * m);
+    for (unsigned k = 0; k < m; k++) {
+      double a = -2.0 * M_PI * (double)k / (double)m;
+      p->mtwd[k].re = cos(a); p->mtwd[k].im = sin(a);
+      p->mtw[k].re = (float)p->mtwd[k].re; p->mtw[k].im = (float)p->mtwd[k].im;
+    }
+  }
   return p;
 }
+
+static unsigned smallest_prime_factor(unsigned n)
+{
+  for (unsigned q = 2; q * q <= n; q++) if (n % q == 0) return q;
+  return n;
+}
+
+/* out[0..n) = DFT_n of in[0], in[stride], in[2 stride] ...; tw = exp(-j 2 pi k / m) with n | m */
+#define LO_MIXED_FFT(NAME, CT, RT)                                                                   \
+static void NAME(const CT *in, CT *out, unsigned n, unsigned stride, const CT *tw, unsigned m)      \
+{                                                                                                    \
+  if (n == 1) { out[0] = in[0]; return; }                                                            \
+  const unsigned p = smallest_prime_factor(n), q = n / p;                                            \
+  for (unsigned r = 0; r < p; r++) NAME(in + r * stride, out + r * q, q, stride * p, tw, m);         \
+  CT y[p];                                                                                           \
+  for (unsigned k = 0; k < q; k++) {                                                                 \
+    for (unsigned r = 0; r < p; r++) {          /* y_r = W_n^(r k) Y_r[k] */                         \
+      const CT w = tw[(size_t)r * k * (m / n) % m], a = out[r * q + k];                              \
+      y[r].re = a.re * w.re - a.im * w.im;                                                           \
+      y[r].im = a.re * w.im + a.im * w.re;                                                           \
+    }                                                                                                \
+    for (unsigned t = 0; t < p; t++) {          /* X[k + q t] = sum_r W_p^(r t) y_r */               \
+      RT sr = y[0].re, si = y[0].im;                                                                 \
+      for (unsigned r = 1; r < p; r++) {                                                             \
+        const CT w = tw[(size_t)(r * t % p) * (m / p)];                                              \
+        sr += y[r].re * w.re - y[r].im * w.im;                                                       \
+        si += y[r].re * w.im + y[r].im * w.re;                                                       \
+      }                                                                                              \
+      out[k + q * t].re = sr; out[k + q * t].im = si;                                                \
+    }                                                                                                \
+  }                                                                                                  \
+}
+LO_MIXED_FFT(mixed_fft_f, lo_c32, float)
+LO_MIXED_FFT(mixed_fft_d, lo_c64, double)
 
 static void fft_destroy(lo_fft *p)
 {
   if (!p) return;
-  free(p->rev); free(p->tw); free(p->twd); free(p->in); free(p->out); free(p->dwork); free(p);
+  free(p->rev); free(p->tw); free(p->twd); free(p->in); free(p->out); free(p->dwork);
+  free(p->mtw); free(p->mtwd); free(p->din); free(p);
 }
 
 /* in -> out, single precision */
 static void fft_execute(lo_fft *p)
 {
   const unsigned m = p->m;
+  if (p->mixed) { mixed_fft_f(p->in, p->out, m, 1, p->mtw, m); return; }
   lo_c32 *x = p->out;
   for (unsigned i = 0; i < m; i++) x[p->rev[i]] = p->in[i];
   for (unsigned len = 2; len <= m; len <<= 1) {
@@ -106,6 +160,11 @@ static void fft_execute(lo_fft *p)
 static void fft_execute_double(lo_fft *p)
 {
   const unsigned m = p->m;
+  if (p->mixed) {
+    for (unsigned i = 0; i < m; i++) { p->din[i].re = p->in[i].re; p->din[i].im = p->in[i].im; }
+    mixed_fft_d(p->din, p->dwork, m, 1, p->mtwd, m);
+    return;
+  }
   lo_c64 *x = p->dwork;
   for (unsigned i = 0; i < m; i++) { x[p->rev[i]].re = p->in[i].re; x[p->rev[i]].im = p->in[i].im; }
   for (unsigned len = 2; len <= m; len <<= 1) {
@@ -294,7 +353,7 @@ static void state_reset_members(lo_demod *d)
 lo_demod *lo_demod_create(unsigned sf, int ldr, float beta, unsigned fft_factor)
 {
   if (sf < 6 || sf > 12 || fft_factor == 0) return NULL;  /* asserts at :70-72 */
-  if (((size_t)fft_factor << sf) > 65535u + 1u) return NULL; /* d_fft_size is unsigned short */
+  if (((size_t)fft_factor << sf) > 65535u) return NULL; /* d_fft_size is unsigned short: 65536 would wrap to 0 */
   lo_demod *d = (lo_demod *)calloc(1, sizeof *d);
   d->d_sf = (unsigned short)sf; d->d_ldr = ldr; d->d_beta = beta;
   d->d_fft_size_factor = (unsigned short)fft_factor;

@@ -66,7 +66,9 @@ def test_argument_checking_without_gpu(g):
     assert lib.lora_hip_demod_create(C.byref(h), 0, 5, 2, 25.0, None, None, None) == g.capi.EINVAL
     assert lib.lora_hip_demod_create(C.byref(h), 0, 13, 2, 25.0, None, None, None) == g.capi.EINVAL
     assert lib.lora_hip_demod_create(C.byref(h), 0, 8, 0, 25.0, None, None, None) == g.capi.EINVAL
-    assert lib.lora_hip_demod_create(C.byref(h), 0, 8, 3, 25.0, None, None, None) == g.capi.EUNSUPPORTED
+    # any fft_factor is taken as long as 2^sf * fft_factor fits the reference's unsigned short d_fft_size
+    assert lib.lora_hip_demod_create(C.byref(h), 0, 12, 16, 25.0, None, None, None) == g.capi.EUNSUPPORTED
+    assert lib.lora_hip_demod_create(C.byref(h), 0, 8, 256, 25.0, None, None, None) == g.capi.EUNSUPPORTED
     assert lib.lora_hip_demod_create(None, 0, 8, 2, 25.0, None, None, None) == g.capi.EINVAL
     up = np.zeros(4, np.complex64)
     assert lib.lora_hip_make_chirp_tables(3, up.ctypes.data, up.ctypes.data) == g.capi.EINVAL

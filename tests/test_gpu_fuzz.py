@@ -24,3 +24,4 @@ def test_random_captures_follow_the_oracle():
         same += r["same_path"]; div += not r["same_path"]; pdus += r["pdus"]
     print(f"{same} identical call paths, {div} sub-margin divergences, {pdus} PDUs")
     assert same >= 380 and pdus >= 300
+

@@ -137,7 +137,7 @@ def test_abi_argument_checking_on_gpu(g):
     assert list(oi.cpu().numpy().view(np.uint16)) == [0, 0xFFFF, 0xFFFF, 0xFFFF]
     assert list(ov.cpu().numpy()) == [0.0, -1.0, -1.0, -1.0]
     with pytest.raises(g.LoraHipError) as e:
-        g.HipDemod(sf, 3, cases.BETA)
+        g.HipDemod(12, 16, cases.BETA)
     assert e.value.code == g.capi.EUNSUPPORTED
     h.close()
 

@@ -4,7 +4,7 @@ Random SF / fft_factor / low_data_rate, packet lengths, gaps (arbitrary sample c
 the squelch threshold, amplitude scaling, and chunked feeding.  Uses the L2 bar of tests/test_gpu_l2_parity.py:
 identical call sequence and PDUs, or a divergence that starts at a window whose top-2 margin is below 1e-4.
 
-  python tools/fuzz_l2.py [seconds] [seed]
+  python tools/fuzz_l2.py [seconds] [seed] [any]      # "any": draw fft_factor from ANY_FACTORS too
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,9 +15,12 @@ import oracle, cases
 from test_gpu_l2_parity import compare_with_oracle
 
 
-def random_case(rng):
+ANY_FACTORS = [1, 2, 4, 3, 3, 5, 6, 7, 8, 12, 15]      # beside the specialised 1/2/4: the any-factor kernels
+
+
+def random_case(rng, factors=(1, 2, 2, 4)):
     sf = int(rng.choice([6, 7, 7, 8, 8, 9, 10, 11, 12]))
-    f = int(rng.choice([1, 2, 2, 4]))
+    f = int(rng.choice(list(factors)))
     ldr = int(rng.integers(0, 2))
     n = 1 << sf
     n_pk = int(rng.integers(1, 5))
@@ -46,10 +49,11 @@ def random_case(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    factors = ANY_FACTORS if len(sys.argv) > 3 and sys.argv[3] == "any" else (1, 2, 2, 4)
     rng = np.random.default_rng(seed)
     t0, n_case, n_same, n_div, n_pdus, n_calls = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
-        sf, f, ldr, cap, chunks = random_case(rng)
+        sf, f, ldr, cap, chunks = random_case(rng, factors)
         try:
             r = compare_with_oracle(g, sf, f, ldr, cap, chunks=chunks, name=f"case {n_case} sf{sf} f{f} ldr{ldr}")
         except AssertionError as e:
