@@ -42,7 +42,14 @@ def test_windows_against_the_oracle(sf, f, g):
     assert h.kernel_name.endswith(",any>")
     idx, val = h.batch(s, g.make_desc(pos, off, kind))
     flips, sub = check_against(idx, val, ri, rv, rm, f"SF{sf} F{f}")
-    assert sub < nwin // 2          # the comparison must not be vacuous
+    if f <= 16:
+        assert sub < nwin // 2      # the comparison must not be vacuous
+    else:
+        # heavy oversampling puts the two bins beside a peak within 1e-4 of each other (margin ~ 1/F^2):
+        # there the index is checked to sit on the same peak instead, within a fraction of one N-point bin
+        m = n * f
+        dist = np.abs(((idx.astype(np.int64) - ri.astype(np.int64)) + m // 2) % m - m // 2)
+        assert dist.max() <= f // 8, f"SF{sf} F{f}: argmax {dist.max()} bins from the oracle's"
     # strided form == descriptor form, bit for bit
     count = (len(s) - n) // n + 1
     i1, v1 = h.batch_strided(s, 0, n, count, chirp_off=n // 8, kind=g.capi.WIN_UP)
