@@ -5,3 +5,4 @@ repository root or with importlib.import_module("gr-lora_amd")."""
 from . import capi  # noqa: F401
 from .capi import HipDemod, LoraHipError, make_chirp_tables, make_kaiser, make_desc  # noqa: F401
 from .demod import demod  # noqa: F401,E402
+from .channelizer import channelizer, create_taps  # noqa: F401,E402

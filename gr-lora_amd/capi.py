@@ -29,6 +29,11 @@ EXPORTS = (
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
     "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset",
+    # include/lora_hip_chan.h
+    "lora_hip_chan_design_taps", "lora_hip_chan_create", "lora_hip_chan_destroy", "lora_hip_chan_set_stream",
+    "lora_hip_chan_last_hip_error", "lora_hip_chan_reset", "lora_hip_chan_output_count", "lora_hip_chan_work",
+    "lora_hip_chan_taps_per_filter", "lora_hip_chan_dec_rate", "lora_hip_chan_flt_rate", "lora_hip_chan_kernel_name",
+    "lora_hip_chan_force_general",
 )
 
 PDU_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint16), C.c_size_t)
@@ -87,6 +92,19 @@ def lib():
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
     L.lora_demod_core_reset.argtypes = [vp]; L.lora_demod_core_reset.restype = i
     L.lora_demod_core_preload.argtypes = [vp, u64, sz, vp, vp]; L.lora_demod_core_preload.restype = i
+    L.lora_hip_chan_design_taps.argtypes = [d, u, d, vp, sz, C.POINTER(sz)]; L.lora_hip_chan_design_taps.restype = i
+    L.lora_hip_chan_create.argtypes = [C.POINTER(vp), i, d, f, vp, sz, u]; L.lora_hip_chan_create.restype = i
+    L.lora_hip_chan_destroy.argtypes = [vp]; L.lora_hip_chan_destroy.restype = None
+    L.lora_hip_chan_set_stream.argtypes = [vp, vp]; L.lora_hip_chan_set_stream.restype = i
+    L.lora_hip_chan_last_hip_error.argtypes = [vp]; L.lora_hip_chan_last_hip_error.restype = C.c_char_p
+    L.lora_hip_chan_reset.argtypes = [vp]; L.lora_hip_chan_reset.restype = i
+    L.lora_hip_chan_output_count.argtypes = [vp, sz]; L.lora_hip_chan_output_count.restype = sz
+    L.lora_hip_chan_work.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), u]; L.lora_hip_chan_work.restype = i
+    for nme in ("lora_hip_chan_taps_per_filter", "lora_hip_chan_dec_rate"):
+        getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = u
+    L.lora_hip_chan_flt_rate.argtypes = [vp]; L.lora_hip_chan_flt_rate.restype = f
+    L.lora_hip_chan_kernel_name.argtypes = [vp]; L.lora_hip_chan_kernel_name.restype = C.c_char_p
+    L.lora_hip_chan_force_general.argtypes = [vp, i]; L.lora_hip_chan_force_general.restype = i
     _lib = L
     return L
 

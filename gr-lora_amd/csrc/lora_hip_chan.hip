@@ -1,0 +1,694 @@
+// lora_hip_chan.hip -- gfx950 channeliser (frequency shift + polyphase arbitrary resampler) and its C ABI
+// (include/lora_hip_chan.h).  Product code: never links or calls anything under oracle/.
+//
+// What it replaces: blocks_rotator_cc and pfb_arb_resampler_ccf in front of lora.demod in the reference's
+// receive flowgraph (examples/rx_usrp.grc:489-503, :825-860).  One pass over the samples in HBM:
+//   * the rotation is applied while a tile is loaded into LDS, from the exact phase (a double per tile, two
+//     small tables inside it) instead of the reference's sample-by-sample float product chain, which cannot
+//     run in parallel and whose rounding depends on the VOLK kernel picked at run time;
+//   * whole-number decimation D (d_flt_rate == 0 and d_dec_rate = D*nfilts: 1 MS/s -> 250 kS/s in the
+//     flowgraph) uses one arm for every output, so the filter bank is a plain decimating FIR:
+//     chan_decim_kernel splits it into its D polyphase components, one lane per component, 16 consecutive
+//     outputs per lane in registers, every LDS value used for up to 16 multiply-adds, then a DPP sum over
+//     the D lanes;
+//   * any other rate runs chan_general_kernel: one output per lane, arm and interpolation weight per output
+//     from the reference's recurrence (computed by the host: it is data-independent), taps applied in the
+//     reference's order with separately rounded products, so it is bit-identical to a sequential float
+//     evaluation when the rotation is off.
+#include "lora_hip_chan.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace lora_chan {
+
+constexpr int kBlock = 256;
+constexpr int kMaxSteps = 24;          // tile loads per thread the rotation table covers
+
+struct CParams {
+  const float2 *in;                    // this call's samples
+  const float2 *carry;                 // the K-1 samples before in[0]
+  long long n_in;
+  float2 *out;
+  unsigned long long n_out;
+  const float *filt, *dfilt;           // [nfilts][K], stored reversed as fir_filter::set_taps does
+  unsigned K, nfilts;
+  unsigned long long p0, dec;          // closed form: output m sits at polyphase position p0 + m*dec
+  const unsigned *sched_pos;           // general form: position per output (relative to in[0]) ...
+  const float *sched_acc;              // ... and d_acc per output
+  unsigned tile_out;                   // general kernel: outputs per tile
+  long long i0;                        // decim kernel: input index of output 0
+  unsigned jfix;                       // decim kernel: the one arm in use
+  double phase0, inc;                  // rotation: angle of sample s (relative to in[0]) = phase0 + inc*s
+  double step_re, step_im;             // decim kernel: exp(i*inc*D*TOB*gridDim.x)
+  const float2 *rot_lane;              // decim kernel: exp(i*inc*t), t < 256
+  float2 rot_step[kMaxSteps];          // decim kernel: exp(i*inc*256*k)
+};
+
+// sample s of the stream (history ++ input), relative to in[0]; zero outside what exists
+__device__ __forceinline__ float2 fetch(const CParams &p, const long long s) {
+  if (s >= 0) return s < p.n_in ? p.in[s] : make_float2(0.0f, 0.0f);
+  const long long c = s + (long long)(p.K - 1);
+  return c >= 0 ? p.carry[c] : make_float2(0.0f, 0.0f);
+}
+// rotator::rotate: z = in * d_phase, separately rounded products
+__device__ __forceinline__ float2 rotate(const float2 x, const float2 ph) {
+  return make_float2(x.x * ph.x - x.y * ph.y, x.x * ph.y + x.y * ph.x);
+}
+__device__ __forceinline__ float2 cmul_f(const float2 a, const float2 b) {
+  return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+
+// ---- any rate ------------------------------------------------------------------------------------------
+// pfb_arb_resampler_ccf::filter, one output per lane.  A tile of outputs shares the span of input samples it
+// touches through LDS (read once from HBM, rotated on the way in).
+template <bool ROT, bool SCHED>
+__global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *tile = reinterpret_cast<float2 *>(smem_raw);
+  const int tid = threadIdx.x;
+  const unsigned K = p.K;
+  const unsigned long long n_tiles = (p.n_out + p.tile_out - 1) / p.tile_out;
+  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const unsigned long long m0 = t * p.tile_out;
+    const unsigned long long m1 = (m0 + p.tile_out < p.n_out) ? m0 + p.tile_out : p.n_out;
+    const unsigned long long pf = SCHED ? (unsigned long long)p.sched_pos[m0] : p.p0 + m0 * p.dec;
+    const unsigned long long pl = SCHED ? (unsigned long long)p.sched_pos[m1 - 1] : p.p0 + (m1 - 1) * p.dec;
+    const long long s_lo = (long long)(pf / p.nfilts) - (long long)(K - 1);
+    const int span = (int)((long long)(pl / p.nfilts) - s_lo + 1);       // host guarantees it fits the tile
+    for (int i = tid; i < span; i += kBlock) {
+      float2 x = fetch(p, s_lo + i);
+      if (ROT) {
+        double sn, cs;
+        sincos(p.phase0 + p.inc * (double)(s_lo + i), &sn, &cs);
+        x = rotate(x, make_float2((float)cs, (float)sn));
+      }
+      tile[i] = x;
+    }
+    __syncthreads();
+    const unsigned long long m = m0 + tid;
+    if (m < m1) {
+      const unsigned long long P = SCHED ? (unsigned long long)p.sched_pos[m] : p.p0 + m * p.dec;
+      const unsigned j = (unsigned)(P % p.nfilts);
+      const float2 *x = tile + ((long long)(P / p.nfilts) - (long long)(K - 1) - s_lo);
+      const float *__restrict__ f0 = p.filt + (size_t)j * K;
+      const float *__restrict__ f1 = p.dfilt + (size_t)j * K;
+      // volk_32fc_32f_dot_prod_32fc (generic): sequential float accumulation, product rounded before the add
+      float re0 = 0, im0 = 0, re1 = 0, im1 = 0;
+      for (unsigned k = 0; k < K; k++) {
+        const float2 v = x[k];
+        const float t0 = f0[k];
+        re0 += v.x * t0; im0 += v.y * t0;
+        if (SCHED) {
+          const float t1 = f1[k];
+          re1 += v.x * t1; im1 += v.y * t1;
+        }
+      }
+      float2 o = make_float2(re0, im0);
+      if (SCHED) {                       // o0 + o1*d_acc; with d_flt_rate == 0 d_acc stays 0 and the term is dropped
+        const float a = p.sched_acc[m];
+        o.x = re0 + re1 * a; o.y = im0 + im1 * a;
+      }
+      p.out[m] = o;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- whole-number decimation ---------------------------------------------------------------------------
+// out[m] = sum_u g[u] * X[i0 + D*m - u], g = the arm's taps in natural order, u < K.  With u = D*q + ph:
+//   out[m] = sum_ph sum_q g[D*q + ph] * Z_ph[m - q],   Z_ph[n] = X[i0 + D*n - ph]
+// D stride-1 filters of Q = ceil(K/D) taps.  Lane (grp, ph) of a workgroup holds 16 consecutive outputs of
+// component ph in registers; its taps stay in VGPRs for the whole launch; a window value read from LDS feeds
+// up to 16 multiply-adds.  LDS holds the tile de-interleaved by component, L[ph][n], rows padded by one per
+// 16 and row length = 16/D (mod 16), which keeps both the de-interleaving writes and the window reads free
+// of bank conflicts.
+template <int D, int NCH>
+struct DecimGeom {
+  static constexpr int Q8 = NCH * 8, R = 16, G = kBlock / D, TOB = R * G;
+  static constexpr int W = TOB + Q8 - 1;                               // window entries per component
+  static constexpr int RL0 = W + (W >> 4) + 1;
+  static constexpr int RL = RL0 + ((16 / D - RL0 % 16) + 16) % 16;     // = 16/D (mod 16)
+  static constexpr int NI = (D * W + kBlock - 1) / kBlock;             // loads per thread per tile
+  static_assert(NI <= kMaxSteps, "rotation step table too small");
+  static_assert((kBlock / D) % 16 == 0, "pad split of the de-interleaving write");
+  static_assert(RL % 16 == (16 / D) % 16, "row length residue");
+};
+
+template <int D, int NCH, bool ROT>
+__global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) {
+  using Gm = DecimGeom<D, NCH>;
+  constexpr int Q8 = Gm::Q8, R = Gm::R, TOB = Gm::TOB, W = Gm::W, RL = Gm::RL, NI = Gm::NI;
+  __shared__ float2 L[D * RL];
+  const int tid = threadIdx.x;
+  const int ph = tid % D, grp = tid / D;
+  const unsigned K = p.K;
+  // this lane's taps: g[D*q + ph] = reversed arm [K-1 - (D*q + ph)], zero beyond the arm
+  float gp[Q8];
+  {
+    const float *__restrict__ arm = p.filt + (size_t)p.jfix * K;
+#pragma unroll
+    for (int q = 0; q < Q8; q++) {
+      const unsigned u = (unsigned)(D * q + ph);
+      gp[q] = u < K ? arm[K - 1 - u] : 0.0f;
+    }
+  }
+  // rotation: phase of the tile's first sample in double, advanced by one grid stride per iteration
+  double br = 1.0, bi = 0.0;
+  float2 lane_rot = make_float2(1.0f, 0.0f);
+  const long long s_first = p.i0 - (long long)D * (Q8 - 1) - (D - 1);   // first sample of tile 0's span
+  if (ROT) {
+    sincos(p.phase0 + p.inc * (double)(s_first + (long long)blockIdx.x * (D * TOB)), &bi, &br);
+    lane_rot = p.rot_lane[tid];
+  }
+  const unsigned long long n_tiles = (p.n_out + TOB - 1) / TOB;
+  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const long long s_lo = s_first + (long long)t * (D * TOB);
+    // ---- load, rotate, de-interleave: stream element e of the span goes to L[D-1 - e%D][e/D] ----
+    {
+      float2 pt = make_float2(1.0f, 0.0f);
+      if (ROT) pt = cmul_f(make_float2((float)br, (float)bi), lane_rot);
+      float2 *row = L + (D - 1 - ph) * RL + grp + (grp >> 4);
+      constexpr int GI = kBlock / D;                                   // e / D = grp + GI*i
+      // pad(grp + GI*i) = pad(grp) + GI*i + (GI*i >> 4): GI*i is a multiple of 16, the two parts never carry
+      // A tile whose span lies inside this call's input (all but the first and last few) loads unconditionally
+      // from a wave-uniform base, NI loads in flight; the edges go one guarded fetch at a time.
+      const bool interior = (s_lo >= 0) && (s_lo + (long long)(NI * kBlock) <= p.n_in);
+      if (interior) {
+        float2 xs[NI];
+        const float2 *__restrict__ src = p.in + s_lo;
+#pragma unroll
+        for (int i = 0; i < NI; i++) xs[i] = src[tid + kBlock * i];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          if (i < NI - 1 || tid + kBlock * i < D * W) {
+            float2 x = xs[i];
+            if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
+            row[GI * i + ((GI * i) >> 4)] = x;
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < NI; i++) {
+          if (tid + kBlock * i < D * W) {
+            float2 x = fetch(p, s_lo + (tid + kBlock * i));
+            if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
+            row[GI * i + ((GI * i) >> 4)] = x;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 16 outputs x Q8 taps of this lane's component --------------------------------------------
+    float2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = make_float2(0.0f, 0.0f);
+    {
+      // window values come from LDS in batches of 8, one batch ahead of the multiply-adds that use it; the
+      // scheduling barriers keep the compiler from hoisting every read to the top (40 values = 80 registers)
+      const float2 *rowp = L + ph * RL + 17 * grp;                     // pad(16*grp + c) = 17*grp + c + (c >> 4)
+      constexpr int NC = R + Q8 - 1, CB = 8, NB = (NC + CB - 1) / CB;
+      float2 xb[2][CB];
+#pragma unroll
+      for (int i = 0; i < CB; i++) xb[0][i] = rowp[i + (i >> 4)];
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int i = 0; i < CB; i++) {
+            const int c = (b + 1) * CB + i;
+            if (c < NC) xb[(b + 1) & 1][i] = rowp[c + (c >> 4)];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < CB; i++) {
+          const int c = b * CB + i;
+          if (c < NC) {
+            const float2 x = xb[b & 1][i];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              const int q = r + Q8 - 1 - c;
+              if (q >= 0 && q < Q8) {
+                acc[r].x = __builtin_fmaf(gp[q], x.x, acc[r].x);
+                acc[r].y = __builtin_fmaf(gp[q], x.y, acc[r].y);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- sum over the D component lanes (DPP), lane ph stores the outputs r = ph (mod D) -----------
+#define CHAN_DPP_ADD(ctrl)                                                                                   \
+    {                                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < R; r++) {                                                        \
+        acc[r].x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[r].x), ctrl, 0xF, 0xF, false)); \
+        acc[r].y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[r].y), ctrl, 0xF, 0xF, false)); \
+      }                                                                                                      \
+    }
+    if (D >= 2) CHAN_DPP_ADD(0xB1)      // quad_perm [1,0,3,2]
+    if (D >= 4) CHAN_DPP_ADD(0x4E)      // quad_perm [2,3,0,1]
+    if (D >= 8) CHAN_DPP_ADD(0x141)     // row_half_mirror
+    if (D >= 16) CHAN_DPP_ADD(0x140)    // row_mirror
+#undef CHAN_DPP_ADD
+    {
+      float2 *__restrict__ ob = p.out + t * TOB;                       // wave-uniform base, 32-bit lane offsets
+      const unsigned long long left = p.n_out - t * TOB;
+      const unsigned lim = left < (unsigned long long)TOB ? (unsigned)left : (unsigned)TOB;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const unsigned o = 16u * grp + r;
+        if ((r % D) == ph && o < lim) ob[o] = acc[r];
+      }
+    }
+    if (ROT) {                          // advance the tile phase by one grid stride (double complex product)
+      const double nr = br * p.step_re - bi * p.step_im, ni = br * p.step_im + bi * p.step_re;
+      br = nr; bi = ni;
+    }
+    __syncthreads();
+  }
+}
+
+// new history = last K-1 samples of (history ++ input)
+__global__ void chan_carry_kernel(const float2 *in, long long n_in, const float2 *old_carry, float2 *new_carry, int k1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k1) return;
+  const long long s = n_in - k1 + i;
+  new_carry[i] = s >= 0 ? in[s] : old_carry[k1 + s];
+}
+
+}  // namespace lora_chan
+
+using lora_chan::CParams;
+
+struct lora_hip_chan {
+  int device = 0;
+  unsigned nfilts = 32, K = 0, dec_rate = 0;
+  float rate = 0, flt_rate = 0;
+  double phase_inc = 0, inc_eff = 0;
+  // stream state (pfb_arb_resampler_ccf: d_last_filter, d_acc; + what a flat-array caller needs)
+  unsigned j = 0, j_init = 0;
+  float acc = 0;
+  size_t skip = 0;                       // inputs of the next call already stepped over
+  unsigned long long n_abs = 0;          // samples consumed so far (rotation phase)
+  bool force_general = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  float *d_filt = nullptr, *d_dfilt = nullptr;
+  float2 *d_carry[2] = {nullptr, nullptr}; int cur_carry = 0;
+  float2 *d_rot_lane = nullptr;
+  float2 *d_in = nullptr; size_t cap_in = 0;
+  float2 *d_out = nullptr; size_t cap_out = 0;
+  unsigned *d_spos = nullptr; float *d_sacc = nullptr; size_t cap_sched = 0;
+  unsigned *h_spos = nullptr; float *h_sacc = nullptr; size_t cap_hsched = 0;   // pinned
+  int num_cu = 256;
+  char hip_err[256] = {0};
+  char kernel_name[64] = {0};
+  // decim dispatch
+  int D = 0, nch = 0;
+};
+
+namespace {
+
+int hip_fail(lora_hip_chan *h, hipError_t e, const char *what) {
+  if (h) snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e));
+  return LORA_HIP_EHIP;
+}
+#define CHAN_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err != hipSuccess) { prev = -1; return; }
+    if (prev == device) { prev = -1; return; }
+    err = hipSetDevice(device);
+    if (err != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+template <typename T>
+int grow(lora_hip_chan *h, T **buf, size_t *cap, size_t want) {
+  if (want <= *cap) return LORA_HIP_OK;
+  if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+  const size_t ncap = want + want / 4;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(buf), ncap * sizeof(T));
+  if (e != hipSuccess) { *buf = nullptr; hip_fail(h, e, "hipMalloc"); return LORA_HIP_ENOMEM; }
+  *cap = ncap;
+  return LORA_HIP_OK;
+}
+
+typedef void (*chan_fn)(const CParams);
+struct DecimVariant { int D, nch; chan_fn fn[2]; int tob, ni; };
+#define CHAN_DV(D, N) {D, N, {&lora_chan::chan_decim_kernel<D, N, false>, &lora_chan::chan_decim_kernel<D, N, true>}, \
+                       lora_chan::DecimGeom<D, N>::TOB, lora_chan::DecimGeom<D, N>::NI}
+const DecimVariant kDecim[] = {
+    CHAN_DV(2, 2), CHAN_DV(2, 3), CHAN_DV(2, 4), CHAN_DV(4, 2), CHAN_DV(4, 3), CHAN_DV(4, 4),
+    CHAN_DV(8, 2), CHAN_DV(8, 3), CHAN_DV(8, 4), CHAN_DV(16, 2), CHAN_DV(16, 3), CHAN_DV(16, 4),
+};
+const DecimVariant *pick_decim(const lora_hip_chan *h) {
+  if (h->force_general || h->flt_rate != 0.0f || h->dec_rate == 0 || h->dec_rate % h->nfilts) return nullptr;
+  const unsigned D = h->dec_rate / h->nfilts;
+  const unsigned q8 = (((h->K + D - 1) / D) + 7) / 8;
+  for (const DecimVariant &v : kDecim) if ((unsigned)v.D == D && (unsigned)v.nch == (q8 < 2 ? 2 : q8)) return &v;
+  return nullptr;
+}
+
+constexpr int kGeneralTileSamples = 6144;       // 48 KiB of LDS per workgroup
+
+// the index recurrence of pfb_arb_resampler_ccf::filter over n_in inputs; stores (position, d_acc) per output
+// when pos != nullptr.  Returns the number of outputs.
+struct Recur { unsigned j; float acc; size_t skip; };
+size_t run_recurrence(const lora_hip_chan *h, Recur &st, size_t n_in, unsigned *pos, float *accs) {
+  size_t i_out = 0, i_in = st.skip;
+  unsigned j = st.j;
+  float acc = st.acc;
+  while (i_in < n_in) {
+    while (j < h->nfilts) {
+      if (pos) { pos[i_out] = (unsigned)(i_in * h->nfilts + j); accs[i_out] = acc; }
+      i_out++;
+      acc += h->flt_rate;
+      j += h->dec_rate + (int)floor(acc);
+      acc = fmodf(acc, 1.0f);
+    }
+    i_in += (size_t)(j / h->nfilts);
+    j = j % h->nfilts;
+  }
+  st.j = j; st.acc = acc; st.skip = i_in - n_in;
+  return i_out;
+}
+
+size_t closed_form_count(const lora_hip_chan *h, size_t n_in, unsigned long long *p0_out) {
+  const unsigned long long p0 = (unsigned long long)h->skip * h->nfilts + h->j;
+  if (p0_out) *p0_out = p0;
+  const unsigned long long end = (unsigned long long)n_in * h->nfilts;
+  if (end <= p0) return 0;
+  return (size_t)((end - p0 + h->dec_rate - 1) / h->dec_rate);
+}
+
+const size_t kGeneralChunk = (size_t)1 << 26;   // positions are 32-bit: nfilts * chunk < 2^32
+
+}  // namespace
+
+extern "C" {
+
+int lora_hip_chan_design_taps(double rate, unsigned nfilts, double atten_db, float *taps, size_t cap, size_t *ntaps) {
+  if (!ntaps || !(rate > 0.0) || nfilts == 0 || !(atten_db > 0.0) || (cap && !taps)) return LORA_HIP_EINVAL;
+  if (rate >= 1.0) return LORA_HIP_EUNSUPPORTED;
+  // pfb.py create_taps, rate < 1: the pass band is 80 % of the output's half band, the transition half of that
+  const double half_band = 0.5 * rate, cutoff = 0.80 * half_band, transition = 0.40 * half_band;
+  const double fs = (double)nfilts;
+  // firdes::compute_ntaps_windes: atten*fs/(22*transition), made odd
+  int n = (int)(atten_db * fs / (22.0 * transition));
+  if (!(n & 1)) n++;
+  if (n < 3) return LORA_HIP_EINVAL;
+  *ntaps = (size_t)n;
+  if (cap == 0) return LORA_HIP_OK;
+  std::vector<float> t((size_t)n);
+  // window.cc blackman_harris (92 dB set) through coswindow, evaluated on a float (ntaps - 1)
+  const float span = (float)(n - 1);
+  const int mid = (n - 1) / 2;
+  const double w0 = 2.0 * M_PI * cutoff / fs;
+  for (int i = 0; i < n; i++) {
+    const float win = (float)(0.35875f - 0.48829f * std::cos((2.0 * M_PI * i) / span) +
+                              0.14128f * std::cos((4.0 * M_PI * i) / span) - 0.01168f * std::cos((6.0 * M_PI * i) / span));
+    const int k = i - mid;
+    // firdes::low_pass_2: truncated sin(x)/x times the window
+    t[(size_t)i] = (k == 0) ? (float)(w0 / M_PI * win) : (float)(std::sin(k * w0) / (k * M_PI) * win);
+  }
+  // unit gain at DC times the requested gain (= nfilts)
+  double dc = t[(size_t)mid];
+  for (int k = 1; k <= mid; k++) dc += 2 * t[(size_t)(mid + k)];
+  const double scale = fs / dc;
+  for (int i = 0; i < n; i++) t[(size_t)i] = (float)(t[(size_t)i] * scale);
+  memcpy(taps, t.data(), sizeof(float) * (cap < (size_t)n ? cap : (size_t)n));
+  return LORA_HIP_OK;
+}
+
+int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, float rate, const float *taps,
+                         size_t ntaps, unsigned nfilts) {
+  if (!out) return LORA_HIP_EINVAL;
+  *out = nullptr;
+  if (!taps || ntaps < 2 || nfilts == 0 || nfilts > 1024 || !(rate > 0.0f) || !std::isfinite(rate) || !std::isfinite(phase_inc))
+    return LORA_HIP_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LORA_HIP_ENODEVICE;
+  if (device < 0 || device >= ndev) return LORA_HIP_ENODEVICE;
+  lora_hip_chan *h = new (std::nothrow) lora_hip_chan();
+  if (!h) return LORA_HIP_ENOMEM;
+  h->device = device; h->nfilts = nfilts; h->rate = rate; h->phase_inc = phase_inc;
+  // pfb_arb_resampler_ccf ctor + set_rate: float arithmetic on an unsigned filter count
+  h->dec_rate = (unsigned)floor(nfilts / rate);
+  h->flt_rate = (nfilts / rate) - h->dec_rate;
+  h->j_init = h->j = (unsigned)((ntaps / 2) % nfilts);
+  h->K = (unsigned)ceil((double)ntaps / (double)nfilts);
+  if (h->dec_rate == 0 && h->flt_rate == 0.0f) { delete h; return LORA_HIP_EINVAL; }
+  // rotator: the per-sample factor is exp(i*(float)phase_inc) rounded to float and normalised; its angle is the
+  // rotation the reference applies per sample
+  if (phase_inc != 0.0) {
+    const float pf = (float)phase_inc;
+    float ir = cosf(pf), ii = sinf(pf);
+    const float mag = hypotf(ir, ii);
+    ir /= mag; ii /= mag;
+    h->inc_eff = atan2((double)ii, (double)ir);
+  }
+  // create_taps / create_diff_taps / fir_filter::set_taps: bank[arm][K-1-q] = taps[arm + q*nfilts]
+  const unsigned K = h->K;
+  std::vector<float> bank((size_t)nfilts * K, 0.0f), dbank((size_t)nfilts * K, 0.0f);
+  for (size_t i = 0; i < ntaps; i++) {
+    const float d = (i + 1 < ntaps) ? (-1.0f * taps[i] + 1.0f * taps[i + 1]) : 0.0f;
+    const size_t arm = i % nfilts, q = i / nfilts;
+    bank[arm * K + (K - 1 - q)] = taps[i];
+    dbank[arm * K + (K - 1 - q)] = d;
+  }
+  auto fail = [&](int code) { lora_hip_chan_destroy(h); return code; };
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(LORA_HIP_EHIP);
+  h->stream = h->own_stream;
+  const size_t bank_bytes = bank.size() * sizeof(float), carry_n = K > 1 ? K - 1 : 1;
+  if (hipMalloc((void **)&h->d_filt, bank_bytes) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_dfilt, bank_bytes) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  for (int c = 0; c < 2; c++) {
+    if (hipMalloc((void **)&h->d_carry[c], carry_n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+    if (hipMemset(h->d_carry[c], 0, carry_n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
+  if (hipMemcpy(h->d_filt, bank.data(), bank_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipMemcpy(h->d_dfilt, dbank.data(), bank_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  {
+    std::vector<float2> lane(lora_chan::kBlock);
+    for (int t = 0; t < lora_chan::kBlock; t++) lane[t] = make_float2((float)std::cos(h->inc_eff * t), (float)std::sin(h->inc_eff * t));
+    if (hipMalloc((void **)&h->d_rot_lane, lane.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+    if (hipMemcpy(h->d_rot_lane, lane.data(), lane.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LORA_HIP_EHIP);
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (K > (unsigned)kGeneralTileSamples - 64) return fail(LORA_HIP_EUNSUPPORTED);
+  {
+    const void *fns[] = {(const void *)&lora_chan::chan_general_kernel<false, false>, (const void *)&lora_chan::chan_general_kernel<true, false>,
+                         (const void *)&lora_chan::chan_general_kernel<false, true>, (const void *)&lora_chan::chan_general_kernel<true, true>};
+    for (const void *f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralTileSamples * 8) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
+  lora_hip_chan_force_general(h, 0);
+  *out = h;
+  return LORA_HIP_OK;
+}
+
+int lora_hip_chan_force_general(lora_hip_chan_t *h, int on) {
+  if (!h) return LORA_HIP_EINVAL;
+  h->force_general = on != 0;
+  const DecimVariant *v = pick_decim(h);
+  if (v) { h->D = v->D; h->nch = v->nch; snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch); }
+  else { h->D = 0; h->nch = 0; snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel"); }
+  return LORA_HIP_OK;
+}
+
+void lora_hip_chan_destroy(lora_hip_chan_t *h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
+  (void)hipFree(h->d_filt); (void)hipFree(h->d_dfilt); (void)hipFree(h->d_carry[0]); (void)hipFree(h->d_carry[1]);
+  (void)hipFree(h->d_rot_lane); (void)hipFree(h->d_in); (void)hipFree(h->d_out); (void)hipFree(h->d_spos); (void)hipFree(h->d_sacc);
+  if (h->h_spos) (void)hipHostFree(h->h_spos);
+  if (h->h_sacc) (void)hipHostFree(h->h_sacc);
+  delete h;
+}
+
+int lora_hip_chan_set_stream(lora_hip_chan_t *h, void *hip_stream) {
+  if (!h) return LORA_HIP_EINVAL;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return LORA_HIP_OK;
+}
+
+const char *lora_hip_chan_last_hip_error(const lora_hip_chan_t *h) { return h ? h->hip_err : ""; }
+unsigned lora_hip_chan_taps_per_filter(const lora_hip_chan_t *h) { return h ? h->K : 0; }
+unsigned lora_hip_chan_dec_rate(const lora_hip_chan_t *h) { return h ? h->dec_rate : 0; }
+float lora_hip_chan_flt_rate(const lora_hip_chan_t *h) { return h ? h->flt_rate : 0.0f; }
+const char *lora_hip_chan_kernel_name(const lora_hip_chan_t *h) { return h ? h->kernel_name : ""; }
+
+int lora_hip_chan_reset(lora_hip_chan_t *h) {
+  if (!h) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  CHAN_TRY(h, guard.err);
+  h->j = h->j_init; h->acc = 0; h->skip = 0; h->n_abs = 0;
+  const size_t carry_n = h->K > 1 ? h->K - 1 : 1;
+  CHAN_TRY(h, hipMemsetAsync(h->d_carry[h->cur_carry], 0, carry_n * sizeof(float2), h->stream));
+  CHAN_TRY(h, hipStreamSynchronize(h->stream));
+  return LORA_HIP_OK;
+}
+
+size_t lora_hip_chan_output_count(lora_hip_chan_t *h, size_t n_in) {
+  if (!h) return 0;
+  if (h->flt_rate == 0.0f) return closed_form_count(h, n_in, nullptr);
+  Recur st{h->j, h->acc, h->skip};
+  return run_recurrence(h, st, n_in, nullptr, nullptr);
+}
+
+static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, float2 *d_out, size_t *n_out) {
+  const bool sched = h->flt_rate != 0.0f;
+  const bool rot = h->phase_inc != 0.0;
+  CParams p;
+  memset(&p, 0, sizeof p);
+  p.in = d_in; p.carry = h->d_carry[h->cur_carry]; p.n_in = (long long)n_in; p.out = d_out;
+  p.filt = h->d_filt; p.dfilt = h->d_dfilt; p.K = h->K; p.nfilts = h->nfilts; p.dec = h->dec_rate;
+  p.inc = h->inc_eff;
+  p.phase0 = rot ? (double)fmodl((long double)h->inc_eff * (long double)h->n_abs, 2.0L * 3.14159265358979323846264338327950288L) : 0.0;
+  size_t cnt;
+  Recur st{h->j, h->acc, h->skip};
+  if (sched) {
+    cnt = run_recurrence(h, st, n_in, nullptr, nullptr);
+    if (cnt) {
+      // the pinned arrays may still feed the previous call's copy
+      CHAN_TRY(h, hipStreamSynchronize(h->stream));
+      if (cnt > h->cap_hsched) {
+        if (h->h_spos) (void)hipHostFree(h->h_spos);
+        if (h->h_sacc) (void)hipHostFree(h->h_sacc);
+        h->h_spos = nullptr; h->h_sacc = nullptr; h->cap_hsched = 0;
+        const size_t ncap = cnt + cnt / 4;
+        if (hipHostMalloc((void **)&h->h_spos, ncap * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return LORA_HIP_ENOMEM;
+        if (hipHostMalloc((void **)&h->h_sacc, ncap * sizeof(float), hipHostMallocDefault) != hipSuccess) return LORA_HIP_ENOMEM;
+        h->cap_hsched = ncap;
+      }
+      if (cnt > h->cap_sched) {
+        size_t c1 = h->cap_sched, c2 = h->cap_sched;
+        int rc;
+        if ((rc = grow(h, &h->d_spos, &c1, cnt)) != LORA_HIP_OK) { h->cap_sched = 0; return rc; }
+        if ((rc = grow(h, &h->d_sacc, &c2, cnt)) != LORA_HIP_OK) { h->cap_sched = 0; return rc; }
+        h->cap_sched = c1 < c2 ? c1 : c2;
+      }
+      Recur st2{h->j, h->acc, h->skip};
+      run_recurrence(h, st2, n_in, h->h_spos, h->h_sacc);
+      CHAN_TRY(h, hipMemcpyAsync(h->d_spos, h->h_spos, cnt * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+      CHAN_TRY(h, hipMemcpyAsync(h->d_sacc, h->h_sacc, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      p.sched_pos = h->d_spos; p.sched_acc = h->d_sacc;
+    }
+  } else {
+    cnt = closed_form_count(h, n_in, &p.p0);
+    const unsigned long long pn = p.p0 + (unsigned long long)cnt * h->dec_rate - (unsigned long long)n_in * h->nfilts;
+    st.j = (unsigned)(pn % h->nfilts); st.skip = (size_t)(pn / h->nfilts); st.acc = 0;
+  }
+  p.n_out = cnt;
+  if (cnt) {
+    const DecimVariant *v = sched ? nullptr : pick_decim(h);
+    if (v) {
+      p.i0 = (long long)(p.p0 / h->nfilts); p.jfix = (unsigned)(p.p0 % h->nfilts);
+      const unsigned long long tiles = (cnt + v->tob - 1) / v->tob;
+      unsigned blocks = (unsigned)h->num_cu * 4;
+      if (tiles < blocks) blocks = (unsigned)tiles;
+      if (rot) {
+        const long double a = (long double)h->inc_eff * (long double)v->D * (long double)v->tob * (long double)blocks;
+        p.step_re = (double)cosl(a); p.step_im = (double)sinl(a);
+        for (int k = 0; k < lora_chan::kMaxSteps; k++) {
+          const double b = h->inc_eff * 256.0 * k;
+          p.rot_step[k] = make_float2((float)std::cos(b), (float)std::sin(b));
+        }
+        p.rot_lane = h->d_rot_lane;
+      }
+      hipLaunchKernelGGL(v->fn[rot ? 1 : 0], dim3(blocks), dim3(lora_chan::kBlock), 0, h->stream, p);
+    } else {
+      // outputs per tile: as many as keep the tile's input span inside the LDS tile
+      unsigned to = lora_chan::kBlock;
+      auto span_of = [&](unsigned t) { return ((unsigned long long)(t - 1) * (h->dec_rate + 1)) / h->nfilts + 2 + h->K; };
+      while (to > 1 && span_of(to) > (unsigned long long)kGeneralTileSamples) to /= 2;
+      if (span_of(to) > (unsigned long long)kGeneralTileSamples) return LORA_HIP_EUNSUPPORTED;
+      p.tile_out = to;
+      const unsigned long long tiles = (cnt + to - 1) / to;
+      unsigned blocks = (unsigned)h->num_cu * 8;
+      if (tiles < blocks) blocks = (unsigned)tiles;
+      const size_t lds = (size_t)kGeneralTileSamples * 8;
+      chan_fn fn = sched ? (rot ? &lora_chan::chan_general_kernel<true, true> : &lora_chan::chan_general_kernel<false, true>)
+                         : (rot ? &lora_chan::chan_general_kernel<true, false> : &lora_chan::chan_general_kernel<false, false>);
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(lora_chan::kBlock), lds, h->stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+  }
+  if (n_in && h->K > 1) {
+    const int k1 = (int)h->K - 1;
+    hipLaunchKernelGGL(lora_chan::chan_carry_kernel, dim3((k1 + 255) / 256), dim3(256), 0, h->stream, d_in, (long long)n_in,
+                       h->d_carry[h->cur_carry], h->d_carry[h->cur_carry ^ 1], k1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+    h->cur_carry ^= 1;
+  }
+  h->j = st.j; h->acc = st.acc; h->skip = st.skip; h->n_abs += n_in;
+  *n_out = cnt;
+  return LORA_HIP_OK;
+}
+
+int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size_t n_in, lora_c32 *out, size_t out_cap,
+                       size_t *n_out, unsigned flags) {
+  if (!h || !n_out || (!in && n_in)) return LORA_HIP_EINVAL;
+  *n_out = 0;
+  const bool in_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
+  if ((flags & LORA_HIP_ASYNC) && (!in_dev || !out_dev)) return LORA_HIP_EINVAL;
+  if (flags & ~(unsigned)(LORA_HIP_IQ_ON_DEVICE | LORA_HIP_OUT_ON_DEVICE | LORA_HIP_ASYNC)) return LORA_HIP_EINVAL;
+  const size_t total = lora_hip_chan_output_count(h, n_in);
+  if (total > out_cap || (total && !out)) return LORA_HIP_EINVAL;
+  if (n_in == 0) return LORA_HIP_OK;
+  DeviceGuard guard(h->device);
+  CHAN_TRY(h, guard.err);
+  int rc;
+  const float2 *d_in = reinterpret_cast<const float2 *>(in);
+  if (!in_dev) {
+    if ((rc = grow(h, &h->d_in, &h->cap_in, n_in)) != LORA_HIP_OK) return rc;
+    CHAN_TRY(h, hipMemcpyAsync(h->d_in, in, n_in * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    d_in = h->d_in;
+  }
+  float2 *d_out = reinterpret_cast<float2 *>(out);
+  if (!out_dev) {
+    if ((rc = grow(h, &h->d_out, &h->cap_out, total ? total : 1)) != LORA_HIP_OK) return rc;
+    d_out = h->d_out;
+  }
+  // the general form carries 32-bit positions: long inputs go through in pieces (any chunking gives the same stream)
+  const size_t piece = (h->flt_rate != 0.0f) ? kGeneralChunk : n_in;
+  size_t done_in = 0, done_out = 0;
+  while (done_in < n_in) {
+    const size_t n = (n_in - done_in < piece) ? n_in - done_in : piece;
+    size_t got = 0;
+    if ((rc = chan_work_chunk(h, d_in + done_in, n, d_out + done_out, &got)) != LORA_HIP_OK) return rc;
+    done_in += n; done_out += got;
+  }
+  if (!out_dev) {
+    if (done_out) CHAN_TRY(h, hipMemcpyAsync(out, d_out, done_out * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+    CHAN_TRY(h, hipStreamSynchronize(h->stream));
+  } else if (!(flags & LORA_HIP_ASYNC) || !in_dev) {
+    CHAN_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  *n_out = done_out;
+  return LORA_HIP_OK;
+}
+
+}  // extern "C"

@@ -22,10 +22,9 @@ TRACE_DTYPE = np.dtype([("pos", "<u8"), ("state", "<u2"), ("chirp_off", "<u2"), 
 
 def build(force=False):
     """Compile oracle/liblora_oracle.so with the committed Makefile (gcc only)."""
-    src = os.path.join(_HERE, "lora_oracle.c")
+    srcs = [os.path.join(_HERE, n) for n in ("lora_oracle.c", "lora_oracle.h", "chan_oracle.c", "chan_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(os.path.join(_HERE, "lora_oracle.h"))):
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(x) for x in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "liblora_oracle.so"])
     return _LIB_PATH
@@ -59,6 +58,16 @@ def lib():
     L.lo_demod_stream.restype = sz
     L.lo_demod_time.argtypes = [u, i, f, u, vp, sz, u, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.lo_demod_time.restype = d
+    # chan_oracle.h
+    L.lo_chan_design_taps.argtypes = [d, u, d, vp, sz]; L.lo_chan_design_taps.restype = sz
+    L.lo_rotator.argtypes = [d, vp, vp, sz, vp, C.POINTER(u)]
+    L.lo_pfb_create.argtypes = [f, vp, sz, u]; L.lo_pfb_create.restype = vp
+    L.lo_pfb_destroy.argtypes = [vp]
+    for n in ("lo_pfb_taps_per_filter", "lo_pfb_dec_rate", "lo_pfb_last_filter"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = u
+    L.lo_pfb_flt_rate.argtypes = [vp]; L.lo_pfb_flt_rate.restype = f
+    L.lo_pfb_work.argtypes = [vp, vp, sz, vp, sz, i]; L.lo_pfb_work.restype = sz
+    L.lo_pfb_schedule.argtypes = [vp, sz, vp, vp, sz]; L.lo_pfb_schedule.restype = sz
     _lib = L
     return L
 
@@ -180,3 +189,62 @@ def time_stream(sf, ldr, beta, fft_factor, capture, reps=1):
     sec = lib().lo_demod_time(sf, int(ldr), beta, fft_factor, _ptr(cap), len(cap), reps,
                               C.byref(nc), C.byref(nf), C.byref(npd))
     return sec, nc.value, nf.value, npd.value
+
+
+# ---- channeliser (chan_oracle.h): rotator_cc + pfb_arb_resampler_ccf, examples/rx_usrp.grc:489-503, :825-860 ----
+def design_taps(rate, nfilts=32, atten=100.0):
+    """pfb.arb_resampler_ccf.create_taps for rate < 1 (firdes.low_pass_2, Blackman-harris)."""
+    n = lib().lo_chan_design_taps(float(rate), nfilts, float(atten), None, 0)
+    t = np.empty(n, np.float32)
+    lib().lo_chan_design_taps(float(rate), nfilts, float(atten), _ptr(t), n)
+    return t
+
+
+class Rotator:
+    """blocks.rotator_cc(phase_inc): float phase recurrence, renormalised every 512 samples."""
+
+    def __init__(self, phase_inc):
+        self.phase_inc = float(phase_inc)
+        self._phase = np.array([1 + 0j], np.complex64)
+        self._counter = C.c_uint(0)
+
+    def work(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.empty_like(x)
+        lib().lo_rotator(self.phase_inc, _ptr(x), _ptr(out), len(x), _ptr(self._phase), C.byref(self._counter))
+        return out
+
+
+class PfbArbResampler:
+    """filter.pfb_arb_resampler_ccf(rate, taps, nfilts) on flat arrays, state carried between calls."""
+
+    def __init__(self, rate, taps=None, nfilts=32, atten=100.0):
+        self.rate, self.nfilts = float(rate), nfilts
+        self.taps = design_taps(rate, nfilts, atten) if taps is None else np.ascontiguousarray(taps, np.float32)
+        self._h = lib().lo_pfb_create(self.rate, _ptr(self.taps), len(self.taps), nfilts)
+        if not self._h:
+            raise ValueError("bad resampler parameters")
+        self.taps_per_filter = lib().lo_pfb_taps_per_filter(self._h)
+        self.dec_rate = lib().lo_pfb_dec_rate(self._h)
+        self.flt_rate = lib().lo_pfb_flt_rate(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().lo_pfb_destroy(self._h)
+            self._h = None
+
+    def max_output(self, n_in):
+        return int(n_in) * self.nfilts // max(1, self.dec_rate) + 2
+
+    def work(self, x, use_double=False):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.empty(self.max_output(len(x)), np.complex64)
+        n = lib().lo_pfb_work(self._h, _ptr(x), len(x), _ptr(out), len(out), int(use_double))
+        return out[:n].copy()
+
+    def schedule(self, n_in):
+        """(32*i_in + j, d_acc) per output for the next n_in inputs; advances the state like work()."""
+        cap = self.max_output(n_in)
+        pos = np.empty(cap, np.uint64); acc = np.empty(cap, np.float32)
+        n = lib().lo_pfb_schedule(self._h, n_in, _ptr(pos), _ptr(acc), cap)
+        return pos[:n].copy(), acc[:n].copy()
