@@ -28,7 +28,8 @@
 namespace lora_chan {
 
 constexpr int kBlock = 256;
-constexpr int kMaxSteps = 24;          // tile loads per thread the rotation table covers
+constexpr int kMaxSteps = 16;          // tile loads per thread the rotation table covers
+constexpr int kFracBits = 24;          // d_acc as an integer count of 2^-24
 
 struct CParams {
   const float2 *in;                    // this call's samples
@@ -38,9 +39,11 @@ struct CParams {
   unsigned long long n_out;
   const float *filt, *dfilt;           // [nfilts][K], stored reversed as fir_filter::set_taps does
   unsigned K, nfilts;
-  unsigned long long p0, dec;          // closed form: output m sits at polyphase position p0 + m*dec
-  const unsigned *sched_pos;           // general form: position per output (relative to in[0]) ...
-  const float *sched_acc;              // ... and d_acc per output
+  // closed form of the reference's index recurrence (exact, see chan_work_chunk): output m sits at polyphase
+  // position p0 + m*dec + ((a0 + m*a) >> 24) relative to in[0], with d_acc = ((a0 + m*a) mod 2^24) / 2^24
+  unsigned long long p0, dec, a0, a;
+  const unsigned *sched_pos;           // fallback form: position per output ...
+  const float *sched_acc;              // ... and d_acc per output, from the host
   unsigned tile_out;                   // general kernel: outputs per tile
   long long i0;                        // decim kernel: input index of output 0
   unsigned jfix;                       // decim kernel: the one arm in use
@@ -50,11 +53,14 @@ struct CParams {
   float2 rot_step[kMaxSteps];          // decim kernel: exp(i*inc*256*k)
 };
 
-// sample s of the stream (history ++ input), relative to in[0]; zero outside what exists
+// sample s of the stream (history ++ input), relative to in[0]; zero outside what exists.  Branch-free: the
+// address is clamped to something valid (the host launches only with n_in >= 1) and the value selected.
 __device__ __forceinline__ float2 fetch(const CParams &p, const long long s) {
-  if (s >= 0) return s < p.n_in ? p.in[s] : make_float2(0.0f, 0.0f);
   const long long c = s + (long long)(p.K - 1);
-  return c >= 0 ? p.carry[c] : make_float2(0.0f, 0.0f);
+  const bool in_main = s >= 0 && s < p.n_in, in_carry = s < 0 && c >= 0;
+  const float2 *ptr = in_main ? p.in + s : (in_carry ? p.carry + c : p.in);
+  const float2 v = *ptr;
+  return (in_main || in_carry) ? v : make_float2(0.0f, 0.0f);
 }
 // rotator::rotate: z = in * d_phase, separately rounded products
 __device__ __forceinline__ float2 rotate(const float2 x, const float2 ph) {
@@ -67,20 +73,25 @@ __device__ __forceinline__ float2 cmul_f(const float2 a, const float2 b) {
 // ---- any rate ------------------------------------------------------------------------------------------
 // pfb_arb_resampler_ccf::filter, one output per lane.  A tile of outputs shares the span of input samples it
 // touches through LDS (read once from HBM, rotated on the way in).
-template <bool ROT, bool SCHED>
+// MODE 0: closed form, d_flt_rate == 0 (one weight-free arm per output); 1: closed form with interpolation;
+// 2: positions and weights from the host (rates above nfilts, where the float recurrence is not exact).
+template <bool ROT, int MODE>
 __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *tile = reinterpret_cast<float2 *>(smem_raw);
   const int tid = threadIdx.x;
   const unsigned K = p.K;
+  constexpr unsigned long long kMask = (1ull << kFracBits) - 1;
+  auto pos = [&](const unsigned long long m) -> unsigned long long {
+    if (MODE == 2) return p.sched_pos[m];
+    return p.p0 + m * p.dec + ((p.a0 + m * p.a) >> kFracBits);
+  };
   const unsigned long long n_tiles = (p.n_out + p.tile_out - 1) / p.tile_out;
   for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const unsigned long long m0 = t * p.tile_out;
     const unsigned long long m1 = (m0 + p.tile_out < p.n_out) ? m0 + p.tile_out : p.n_out;
-    const unsigned long long pf = SCHED ? (unsigned long long)p.sched_pos[m0] : p.p0 + m0 * p.dec;
-    const unsigned long long pl = SCHED ? (unsigned long long)p.sched_pos[m1 - 1] : p.p0 + (m1 - 1) * p.dec;
-    const long long s_lo = (long long)(pf / p.nfilts) - (long long)(K - 1);
-    const int span = (int)((long long)(pl / p.nfilts) - s_lo + 1);       // host guarantees it fits the tile
+    const long long s_lo = (long long)(pos(m0) / p.nfilts) - (long long)(K - 1);
+    const int span = (int)((long long)(pos(m1 - 1) / p.nfilts) - s_lo + 1);   // host guarantees it fits the tile
     for (int i = tid; i < span; i += kBlock) {
       float2 x = fetch(p, s_lo + i);
       if (ROT) {
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
     __syncthreads();
     const unsigned long long m = m0 + tid;
     if (m < m1) {
-      const unsigned long long P = SCHED ? (unsigned long long)p.sched_pos[m] : p.p0 + m * p.dec;
+      const unsigned long long P = pos(m);
       const unsigned j = (unsigned)(P % p.nfilts);
       const float2 *x = tile + ((long long)(P / p.nfilts) - (long long)(K - 1) - s_lo);
       const float *__restrict__ f0 = p.filt + (size_t)j * K;
@@ -104,14 +115,15 @@ __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
         const float2 v = x[k];
         const float t0 = f0[k];
         re0 += v.x * t0; im0 += v.y * t0;
-        if (SCHED) {
+        if (MODE != 0) {
           const float t1 = f1[k];
           re1 += v.x * t1; im1 += v.y * t1;
         }
       }
       float2 o = make_float2(re0, im0);
-      if (SCHED) {                       // o0 + o1*d_acc; with d_flt_rate == 0 d_acc stays 0 and the term is dropped
-        const float a = p.sched_acc[m];
+      if (MODE != 0) {                   // o0 + o1*d_acc; with d_flt_rate == 0 d_acc stays 0 and the term is dropped
+        const float a = (MODE == 2) ? p.sched_acc[m]
+                                    : (float)((p.a0 + m * p.a) & kMask) * (1.0f / (float)(1u << kFracBits));
         o.x = re0 + re1 * a; o.y = im0 + im1 * a;
       }
       p.out[m] = o;
@@ -123,21 +135,22 @@ __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
 // ---- whole-number decimation ---------------------------------------------------------------------------
 // out[m] = sum_u g[u] * X[i0 + D*m - u], g = the arm's taps in natural order, u < K.  With u = D*q + ph:
 //   out[m] = sum_ph sum_q g[D*q + ph] * Z_ph[m - q],   Z_ph[n] = X[i0 + D*n - ph]
-// D stride-1 filters of Q = ceil(K/D) taps.  Lane (grp, ph) of a workgroup holds 16 consecutive outputs of
+// D stride-1 filters of Q = ceil(K/D) taps.  Lane (grp, ph) of a workgroup holds R = 8 consecutive outputs of
 // component ph in registers; its taps stay in VGPRs for the whole launch; a window value read from LDS feeds
-// up to 16 multiply-adds.  LDS holds the tile de-interleaved by component, L[ph][n], rows padded by one per
-// 16 and row length = 16/D (mod 16), which keeps both the de-interleaving writes and the window reads free
-// of bank conflicts.
+// up to 8 multiply-adds.  LDS holds the tile de-interleaved by component, L[ph][n], rows padded by one per 8
+// and row length = 16/D (mod 16), which keeps both the de-interleaving writes and the window reads free of
+// bank conflicts.  The next tile's samples are loaded into registers before the multiply-adds of the current
+// one start, so that HBM latency hides behind them.
 template <int D, int NCH>
 struct DecimGeom {
-  static constexpr int Q8 = NCH * 8, R = 16, G = kBlock / D, TOB = R * G;
+  static constexpr int Q8 = NCH * 8, R = 8, G = kBlock / D, TOB = R * G;
   static constexpr int W = TOB + Q8 - 1;                               // window entries per component
-  static constexpr int RL0 = W + (W >> 4) + 1;
+  static constexpr int RL0 = W + (W >> 3) + 1;
   static constexpr int RL = RL0 + ((16 / D - RL0 % 16) + 16) % 16;     // = 16/D (mod 16)
   static constexpr int NI = (D * W + kBlock - 1) / kBlock;             // loads per thread per tile
   static_assert(NI <= kMaxSteps, "rotation step table too small");
-  static_assert((kBlock / D) % 16 == 0, "pad split of the de-interleaving write");
   static_assert(RL % 16 == (16 / D) % 16, "row length residue");
+  static_assert((kBlock / D) % 8 == 0 && R % 8 == 0, "pad split: thread part and constant part never carry");
 };
 
 template <int D, int NCH, bool ROT>
@@ -167,62 +180,65 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
     lane_rot = p.rot_lane[tid];
   }
   const unsigned long long n_tiles = (p.n_out + TOB - 1) / TOB;
-  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  // A tile whose span lies inside this call's input (all but the first and last few) loads unconditionally
+  // from a wave-uniform base; the edges go through the guarded fetch.
+  float2 xs[NI];
+  auto load_tile = [&](const unsigned long long t) {
     const long long s_lo = s_first + (long long)t * (D * TOB);
-    // ---- load, rotate, de-interleave: stream element e of the span goes to L[D-1 - e%D][e/D] ----
+    const bool interior = (s_lo >= 0) && (s_lo + (long long)(NI * kBlock) <= p.n_in);
+    if (interior) {
+      const float2 *__restrict__ src = p.in + s_lo;
+#pragma unroll
+      for (int i = 0; i < NI; i++) xs[i] = src[tid + kBlock * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; i++) xs[i] = fetch(p, s_lo + (tid + kBlock * i));
+    }
+  };
+  unsigned long long t = blockIdx.x;
+  if (t < n_tiles) load_tile(t);
+  while (t < n_tiles) {
+    // ---- rotate, de-interleave: stream element e of the span goes to L[D-1 - e%D][e/D] -----------
     {
       float2 pt = make_float2(1.0f, 0.0f);
       if (ROT) pt = cmul_f(make_float2((float)br, (float)bi), lane_rot);
-      float2 *row = L + (D - 1 - ph) * RL + grp + (grp >> 4);
-      constexpr int GI = kBlock / D;                                   // e / D = grp + GI*i
-      // pad(grp + GI*i) = pad(grp) + GI*i + (GI*i >> 4): GI*i is a multiple of 16, the two parts never carry
-      // A tile whose span lies inside this call's input (all but the first and last few) loads unconditionally
-      // from a wave-uniform base, NI loads in flight; the edges go one guarded fetch at a time.
-      const bool interior = (s_lo >= 0) && (s_lo + (long long)(NI * kBlock) <= p.n_in);
-      if (interior) {
-        float2 xs[NI];
-        const float2 *__restrict__ src = p.in + s_lo;
+      float2 *row = L + (D - 1 - ph) * RL + grp + (grp >> 3);
+      constexpr int GI = kBlock / D;                                   // e / D = grp + GI*i; GI*i is a multiple of 8
 #pragma unroll
-        for (int i = 0; i < NI; i++) xs[i] = src[tid + kBlock * i];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-          if (i < NI - 1 || tid + kBlock * i < D * W) {
-            float2 x = xs[i];
-            if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
-            row[GI * i + ((GI * i) >> 4)] = x;
-          }
+      for (int i = 0; i < NI; i++) {
+        if (i < NI - 1 || tid + kBlock * i < D * W) {
+          float2 x = xs[i];
+          if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
+          row[GI * i + ((GI * i) >> 3)] = x;
         }
-      } else {
-#pragma unroll 1
-        for (int i = 0; i < NI; i++) {
-          if (tid + kBlock * i < D * W) {
-            float2 x = fetch(p, s_lo + (tid + kBlock * i));
-            if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
-            row[GI * i + ((GI * i) >> 4)] = x;
-          }
-        }
+      }
+      if (ROT) {                        // advance the tile phase by one grid stride (double complex product)
+        const double nr = br * p.step_re - bi * p.step_im, ni = br * p.step_im + bi * p.step_re;
+        br = nr; bi = ni;
       }
     }
     __syncthreads();
-    // ---- 16 outputs x Q8 taps of this lane's component --------------------------------------------
+    const unsigned long long t_next = t + gridDim.x;
+    if (t_next < n_tiles) load_tile(t_next);                           // in flight during the multiply-adds below
+    // ---- R outputs x Q8 taps of this lane's component ---------------------------------------------
     float2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = make_float2(0.0f, 0.0f);
     {
       // window values come from LDS in batches of 8, one batch ahead of the multiply-adds that use it; the
-      // scheduling barriers keep the compiler from hoisting every read to the top (40 values = 80 registers)
-      const float2 *rowp = L + ph * RL + 17 * grp;                     // pad(16*grp + c) = 17*grp + c + (c >> 4)
+      // scheduling barriers keep the compiler from hoisting every read to the top
+      const float2 *rowp = L + ph * RL + (R + R / 8) * grp;             // pad(R*grp + c) = 9*grp + c + (c >> 3)
       constexpr int NC = R + Q8 - 1, CB = 8, NB = (NC + CB - 1) / CB;
       float2 xb[2][CB];
 #pragma unroll
-      for (int i = 0; i < CB; i++) xb[0][i] = rowp[i + (i >> 4)];
+      for (int i = 0; i < CB; i++) xb[0][i] = rowp[i + (i >> 3)];
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         if (b + 1 < NB) {
 #pragma unroll
           for (int i = 0; i < CB; i++) {
             const int c = (b + 1) * CB + i;
-            if (c < NC) xb[(b + 1) & 1][i] = rowp[c + (c >> 4)];
+            if (c < NC) xb[(b + 1) & 1][i] = rowp[c + (c >> 3)];
           }
         }
 #pragma unroll
@@ -257,20 +273,38 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
     if (D >= 16) CHAN_DPP_ADD(0x140)    // row_mirror
 #undef CHAN_DPP_ADD
     {
+      // every lane of a group holds all R sums now; lane ph keeps the PER consecutive outputs ph*PER.. (a select
+      // chain over compile-time register indices) so that a wave stores one contiguous run, 16 bytes per lane
+      constexpr int PER = (D <= R) ? R / D : 1, ACT = (D <= R) ? D : R;   // outputs per lane, storing lanes per group
+      float2 mine[PER];
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        mine[i] = acc[i];
+#pragma unroll
+        for (int c = 1; c < ACT; c++) {
+          if (ph == c) mine[i] = acc[c * PER + i];
+        }
+      }
       float2 *__restrict__ ob = p.out + t * TOB;                       // wave-uniform base, 32-bit lane offsets
       const unsigned long long left = p.n_out - t * TOB;
       const unsigned lim = left < (unsigned long long)TOB ? (unsigned)left : (unsigned)TOB;
+      const unsigned o = (unsigned)(R * grp + ph * PER);
+      if (ph < ACT) {
+        if (o + PER <= lim) {
+          if constexpr (PER == 1) ob[o] = mine[0];
+          else {
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const unsigned o = 16u * grp + r;
-        if ((r % D) == ph && o < lim) ob[o] = acc[r];
+            for (int i = 0; i < PER; i += 2)
+              *reinterpret_cast<float4 *>(ob + o + i) = make_float4(mine[i].x, mine[i].y, mine[i + 1].x, mine[i + 1].y);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < PER; i++) if (o + i < lim) ob[o + i] = mine[i];
+        }
       }
     }
-    if (ROT) {                          // advance the tile phase by one grid stride (double complex product)
-      const double nr = br * p.step_re - bi * p.step_im, ni = br * p.step_im + bi * p.step_re;
-      br = nr; bi = ni;
-    }
-    __syncthreads();
+    __syncthreads();                    // every lane has read its windows before the tile is overwritten
+    t = t_next;
   }
 }
 
@@ -296,6 +330,9 @@ struct lora_hip_chan {
   float acc = 0;
   size_t skip = 0;                       // inputs of the next call already stepped over
   unsigned long long n_abs = 0;          // samples consumed so far (rotation phase)
+  // d_flt_rate as an integer count of 2^-24 when the float recurrence is exact (see frac_exact below)
+  bool frac = false;
+  unsigned long long a = 0;
   bool force_general = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   float *d_filt = nullptr, *d_dfilt = nullptr;
@@ -308,8 +345,6 @@ struct lora_hip_chan {
   int num_cu = 256;
   char hip_err[256] = {0};
   char kernel_name[64] = {0};
-  // decim dispatch
-  int D = 0, nch = 0;
 };
 
 namespace {
@@ -363,9 +398,11 @@ const DecimVariant *pick_decim(const lora_hip_chan *h) {
 }
 
 constexpr int kGeneralTileSamples = 6144;       // 48 KiB of LDS per workgroup
+constexpr int kFracBits = lora_chan::kFracBits;
+constexpr unsigned long long kFracMask = (1ull << kFracBits) - 1;
 
-// the index recurrence of pfb_arb_resampler_ccf::filter over n_in inputs; stores (position, d_acc) per output
-// when pos != nullptr.  Returns the number of outputs.
+// The index recurrence of pfb_arb_resampler_ccf::filter, step by step (float d_acc, fmodf), over n_in inputs;
+// stores (position, d_acc) per output when pos != nullptr.  Used where the closed form below does not hold.
 struct Recur { unsigned j; float acc; size_t skip; };
 size_t run_recurrence(const lora_hip_chan *h, Recur &st, size_t n_in, unsigned *pos, float *accs) {
   size_t i_out = 0, i_in = st.skip;
@@ -386,15 +423,35 @@ size_t run_recurrence(const lora_hip_chan *h, Recur &st, size_t n_in, unsigned *
   return i_out;
 }
 
-size_t closed_form_count(const lora_hip_chan *h, size_t n_in, unsigned long long *p0_out) {
-  const unsigned long long p0 = (unsigned long long)h->skip * h->nfilts + h->j;
-  if (p0_out) *p0_out = p0;
-  const unsigned long long end = (unsigned long long)n_in * h->nfilts;
+// Closed form of the same recurrence.  v = nfilts/rate is a float >= 1, so d_flt_rate = v - floor(v) is a
+// multiple of ulp(v) >= 2^-23, d_acc + d_flt_rate < 2 has at most 24 significant bits, and every float
+// operation of the recurrence (the add, floor, fmodf) is exact: d_acc is an integer count of 2^-24 that
+// advances by a = d_flt_rate * 2^24 modulo 2^24, and the carries are what floor(d_acc) adds to j.  Output k
+// after a state (P0 = nfilts*skip + j, A0) therefore sits at P0 + k*dec + ((A0 + k*a) >> 24) with weight
+// ((A0 + k*a) mod 2^24) / 2^24: no sequential pass, and the kernel evaluates it per lane.
+typedef unsigned __int128 u128;
+inline u128 frac_pos(const lora_hip_chan *h, u128 p0, unsigned long long a0, u128 k) {
+  return p0 + k * h->dec_rate + ((a0 + k * h->a) >> kFracBits);
+}
+// number of outputs over n_in inputs = first k with position >= nfilts*n_in (positions never decrease)
+size_t frac_count(const lora_hip_chan *h, size_t n_in, unsigned long long *p0_out, unsigned long long *a0_out) {
+  const u128 p0 = (u128)h->skip * h->nfilts + h->j;
+  const unsigned long long a0 = (unsigned long long)ldexpf(h->acc, kFracBits);
+  if (p0_out) *p0_out = (unsigned long long)p0;
+  if (a0_out) *a0_out = a0;
+  const u128 end = (u128)n_in * h->nfilts;
   if (end <= p0) return 0;
-  return (size_t)((end - p0 + h->dec_rate - 1) / h->dec_rate);
+  u128 lo = 0, hi;                               // invariant: pos(lo) < end <= pos(hi)
+  if (h->dec_rate) hi = (end - p0) / h->dec_rate + 1;
+  else hi = (((end - p0) << kFracBits) / h->a) + 2;
+  while (hi - lo > 1) {
+    const u128 mid = lo + (hi - lo) / 2;
+    if (frac_pos(h, p0, a0, mid) < end) lo = mid; else hi = mid;
+  }
+  return (size_t)hi;
 }
 
-const size_t kGeneralChunk = (size_t)1 << 26;   // positions are 32-bit: nfilts * chunk < 2^32
+const size_t kSchedChunk = (size_t)1 << 26;     // fallback positions are 32-bit: nfilts * chunk < 2^32
 
 }  // namespace
 
@@ -446,11 +503,18 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
   if (!h) return LORA_HIP_ENOMEM;
   h->device = device; h->nfilts = nfilts; h->rate = rate; h->phase_inc = phase_inc;
   // pfb_arb_resampler_ccf ctor + set_rate: float arithmetic on an unsigned filter count
-  h->dec_rate = (unsigned)floor(nfilts / rate);
-  h->flt_rate = (nfilts / rate) - h->dec_rate;
+  const float v = nfilts / rate;
+  if (!(v < 1.0e9f)) { delete h; return LORA_HIP_EINVAL; }
+  h->dec_rate = (unsigned)floor(v);
+  h->flt_rate = v - h->dec_rate;
   h->j_init = h->j = (unsigned)((ntaps / 2) % nfilts);
   h->K = (unsigned)ceil((double)ntaps / (double)nfilts);
   if (h->dec_rate == 0 && h->flt_rate == 0.0f) { delete h; return LORA_HIP_EINVAL; }
+  {
+    const float scaled = ldexpf(h->flt_rate, kFracBits);
+    h->frac = (v >= 1.0f) && (scaled == floorf(scaled));
+    h->a = h->frac ? (unsigned long long)scaled : 0;
+  }
   // rotator: the per-sample factor is exp(i*(float)phase_inc) rounded to float and normalised; its angle is the
   // rotation the reference applies per sample
   if (phase_inc != 0.0) {
@@ -496,8 +560,9 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
   }
   if (K > (unsigned)kGeneralTileSamples - 64) return fail(LORA_HIP_EUNSUPPORTED);
   {
-    const void *fns[] = {(const void *)&lora_chan::chan_general_kernel<false, false>, (const void *)&lora_chan::chan_general_kernel<true, false>,
-                         (const void *)&lora_chan::chan_general_kernel<false, true>, (const void *)&lora_chan::chan_general_kernel<true, true>};
+    const void *fns[] = {(const void *)&lora_chan::chan_general_kernel<false, 0>, (const void *)&lora_chan::chan_general_kernel<true, 0>,
+                         (const void *)&lora_chan::chan_general_kernel<false, 1>, (const void *)&lora_chan::chan_general_kernel<true, 1>,
+                         (const void *)&lora_chan::chan_general_kernel<false, 2>, (const void *)&lora_chan::chan_general_kernel<true, 2>};
     for (const void *f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralTileSamples * 8) != hipSuccess) return fail(LORA_HIP_EHIP);
   }
@@ -510,8 +575,8 @@ int lora_hip_chan_force_general(lora_hip_chan_t *h, int on) {
   if (!h) return LORA_HIP_EINVAL;
   h->force_general = on != 0;
   const DecimVariant *v = pick_decim(h);
-  if (v) { h->D = v->D; h->nch = v->nch; snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch); }
-  else { h->D = 0; h->nch = 0; snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel"); }
+  if (v) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch);
+  else snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel");
   return LORA_HIP_OK;
 }
 
@@ -551,23 +616,30 @@ int lora_hip_chan_reset(lora_hip_chan_t *h) {
 
 size_t lora_hip_chan_output_count(lora_hip_chan_t *h, size_t n_in) {
   if (!h) return 0;
-  if (h->flt_rate == 0.0f) return closed_form_count(h, n_in, nullptr);
+  if (h->frac) return frac_count(h, n_in, nullptr, nullptr);
   Recur st{h->j, h->acc, h->skip};
   return run_recurrence(h, st, n_in, nullptr, nullptr);
 }
 
 static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, float2 *d_out, size_t *n_out) {
-  const bool sched = h->flt_rate != 0.0f;
   const bool rot = h->phase_inc != 0.0;
   CParams p;
   memset(&p, 0, sizeof p);
   p.in = d_in; p.carry = h->d_carry[h->cur_carry]; p.n_in = (long long)n_in; p.out = d_out;
-  p.filt = h->d_filt; p.dfilt = h->d_dfilt; p.K = h->K; p.nfilts = h->nfilts; p.dec = h->dec_rate;
+  p.filt = h->d_filt; p.dfilt = h->d_dfilt; p.K = h->K; p.nfilts = h->nfilts; p.dec = h->dec_rate; p.a = h->a;
   p.inc = h->inc_eff;
   p.phase0 = rot ? (double)fmodl((long double)h->inc_eff * (long double)h->n_abs, 2.0L * 3.14159265358979323846264338327950288L) : 0.0;
   size_t cnt;
   Recur st{h->j, h->acc, h->skip};
-  if (sched) {
+  int mode;
+  if (h->frac) {
+    cnt = frac_count(h, n_in, &p.p0, &p.a0);
+    const u128 pn = frac_pos(h, p.p0, p.a0, cnt) - (u128)n_in * h->nfilts;      // position of the next output
+    st.j = (unsigned)(pn % h->nfilts); st.skip = (size_t)(pn / h->nfilts);
+    st.acc = ldexpf((float)((p.a0 + (unsigned long long)cnt * h->a) & kFracMask), -kFracBits);
+    mode = (h->a == 0 && p.a0 == 0) ? 0 : 1;
+  } else {
+    mode = 2;
     cnt = run_recurrence(h, st, n_in, nullptr, nullptr);
     if (cnt) {
       // the pinned arrays may still feed the previous call's copy
@@ -594,14 +666,10 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
       CHAN_TRY(h, hipMemcpyAsync(h->d_sacc, h->h_sacc, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
       p.sched_pos = h->d_spos; p.sched_acc = h->d_sacc;
     }
-  } else {
-    cnt = closed_form_count(h, n_in, &p.p0);
-    const unsigned long long pn = p.p0 + (unsigned long long)cnt * h->dec_rate - (unsigned long long)n_in * h->nfilts;
-    st.j = (unsigned)(pn % h->nfilts); st.skip = (size_t)(pn / h->nfilts); st.acc = 0;
   }
   p.n_out = cnt;
   if (cnt) {
-    const DecimVariant *v = sched ? nullptr : pick_decim(h);
+    const DecimVariant *v = (mode == 0) ? pick_decim(h) : nullptr;
     if (v) {
       p.i0 = (long long)(p.p0 / h->nfilts); p.jfix = (unsigned)(p.p0 % h->nfilts);
       const unsigned long long tiles = (cnt + v->tob - 1) / v->tob;
@@ -628,8 +696,10 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
       unsigned blocks = (unsigned)h->num_cu * 8;
       if (tiles < blocks) blocks = (unsigned)tiles;
       const size_t lds = (size_t)kGeneralTileSamples * 8;
-      chan_fn fn = sched ? (rot ? &lora_chan::chan_general_kernel<true, true> : &lora_chan::chan_general_kernel<false, true>)
-                         : (rot ? &lora_chan::chan_general_kernel<true, false> : &lora_chan::chan_general_kernel<false, false>);
+      chan_fn fn;
+      if (mode == 0) fn = rot ? &lora_chan::chan_general_kernel<true, 0> : &lora_chan::chan_general_kernel<false, 0>;
+      else if (mode == 1) fn = rot ? &lora_chan::chan_general_kernel<true, 1> : &lora_chan::chan_general_kernel<false, 1>;
+      else fn = rot ? &lora_chan::chan_general_kernel<true, 2> : &lora_chan::chan_general_kernel<false, 2>;
       hipLaunchKernelGGL(fn, dim3(blocks), dim3(lora_chan::kBlock), lds, h->stream, p);
     }
     hipError_t e = hipGetLastError();
@@ -655,6 +725,7 @@ int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size_t n_in, lora
   const bool in_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
   if ((flags & LORA_HIP_ASYNC) && (!in_dev || !out_dev)) return LORA_HIP_EINVAL;
   if (flags & ~(unsigned)(LORA_HIP_IQ_ON_DEVICE | LORA_HIP_OUT_ON_DEVICE | LORA_HIP_ASYNC)) return LORA_HIP_EINVAL;
+  if (n_in > ((size_t)1 << 56)) return LORA_HIP_EINVAL;
   const size_t total = lora_hip_chan_output_count(h, n_in);
   if (total > out_cap || (total && !out)) return LORA_HIP_EINVAL;
   if (n_in == 0) return LORA_HIP_OK;
@@ -672,8 +743,8 @@ int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size_t n_in, lora
     if ((rc = grow(h, &h->d_out, &h->cap_out, total ? total : 1)) != LORA_HIP_OK) return rc;
     d_out = h->d_out;
   }
-  // the general form carries 32-bit positions: long inputs go through in pieces (any chunking gives the same stream)
-  const size_t piece = (h->flt_rate != 0.0f) ? kGeneralChunk : n_in;
+  // the fallback form carries 32-bit positions: long inputs go through in pieces (any chunking gives the same stream)
+  const size_t piece = h->frac ? n_in : kSchedChunk;
   size_t done_in = 0, done_out = 0;
   while (done_in < n_in) {
     const size_t n = (n_in - done_in < piece) ? n_in - done_in : piece;
@@ -684,7 +755,7 @@ int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size_t n_in, lora
   if (!out_dev) {
     if (done_out) CHAN_TRY(h, hipMemcpyAsync(out, d_out, done_out * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
     CHAN_TRY(h, hipStreamSynchronize(h->stream));
-  } else if (!(flags & LORA_HIP_ASYNC) || !in_dev) {
+  } else if (!(flags & LORA_HIP_ASYNC)) {
     CHAN_TRY(h, hipStreamSynchronize(h->stream));
   }
   *n_out = done_out;

@@ -234,7 +234,7 @@ class PfbArbResampler:
             self._h = None
 
     def max_output(self, n_in):
-        return int(n_in) * self.nfilts // max(1, self.dec_rate) + 2
+        return int(int(n_in) * self.rate * (1 + 1e-6)) + 64        # one output per (dec_rate + flt_rate) positions
 
     def work(self, x, use_double=False):
         x = np.ascontiguousarray(x, np.complex64)
