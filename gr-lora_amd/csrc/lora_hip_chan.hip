@@ -175,8 +175,13 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
   double br = 1.0, bi = 0.0;
   float2 lane_rot = make_float2(1.0f, 0.0f);
   const long long s_first = p.i0 - (long long)D * (Q8 - 1) - (D - 1);   // first sample of tile 0's span
+  // Workgroups are dealt to the 8 XCDs round robin; neighbouring tiles share D*(Q8-1) samples of halo, so tile
+  // numbers are handed out such that neighbours run on one XCD at about the same time and the halo is read from
+  // HBM once, into that XCD's L2 (measured before: 13 % more HBM reads than input bytes).
+  unsigned lb = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (ROT) {
-    sincos(p.phase0 + p.inc * (double)(s_first + (long long)blockIdx.x * (D * TOB)), &bi, &br);
+    sincos(p.phase0 + p.inc * (double)(s_first + (long long)lb * (D * TOB)), &bi, &br);
     lane_rot = p.rot_lane[tid];
   }
   const unsigned long long n_tiles = (p.n_out + TOB - 1) / TOB;
@@ -185,17 +190,19 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
   float2 xs[NI];
   auto load_tile = [&](const unsigned long long t) {
     const long long s_lo = s_first + (long long)t * (D * TOB);
-    const bool interior = (s_lo >= 0) && (s_lo + (long long)(NI * kBlock) <= p.n_in);
+    const bool interior = (s_lo >= 0) && (s_lo + (long long)(D * W) <= p.n_in);
     if (interior) {
       const float2 *__restrict__ src = p.in + s_lo;
 #pragma unroll
-      for (int i = 0; i < NI; i++) xs[i] = src[tid + kBlock * i];
+      for (int i = 0; i < NI; i++) {
+        if (i < NI - 1 || tid + kBlock * i < D * W) xs[i] = src[tid + kBlock * i];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NI; i++) xs[i] = fetch(p, s_lo + (tid + kBlock * i));
     }
   };
-  unsigned long long t = blockIdx.x;
+  unsigned long long t = lb;
   if (t < n_tiles) load_tile(t);
   while (t < n_tiles) {
     // ---- rotate, de-interleave: stream element e of the span goes to L[D-1 - e%D][e/D] -----------
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
       for (int i = 0; i < NI; i++) {
         if (i < NI - 1 || tid + kBlock * i < D * W) {
           float2 x = xs[i];
-          if (ROT) x = rotate(x, cmul_f(pt, p.rot_step[i]));
+          if (ROT) x = cmul_f(x, cmul_f(pt, p.rot_step[i]));             // FMA form: the phase is exact here, the product order is not the contract
           row[GI * i + ((GI * i) >> 3)] = x;
         }
       }
