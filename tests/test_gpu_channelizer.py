@@ -211,3 +211,57 @@ def test_wideband_capture_to_pdus(sf, f, g):
         assert len(got_pdus[0]) == len(want_pdus[0])
         assert np.array_equal(np.asarray(got_pdus[0])[:-1], want_pdus[0][:-1]), f"channel {k}"
         ch.close()
+
+
+def test_random_streams_follow_the_oracle(g):
+    """Seeded differential run: random rates (whole-number, fractional, interpolating), prototype lengths, offsets
+    and chunkings, including chunks shorter than the history and streams shorter than one arm.  Rotation off:
+    exact (general kernel) or 2e-6 of the RMS (decimation kernel); rotation on: drift-corrected 5e-5."""
+    rng = np.random.default_rng(4242)
+    exact = close = rotated = 0
+    for case in range(120):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            rate = 1.0 / float(rng.choice([2, 4, 8, 16]))
+            taps = None if rng.random() < 0.5 else oracle.design_taps(rate, atten=float(rng.choice([40, 80, 120])))
+        elif kind == 1:
+            rate = float(rng.uniform(0.03, 0.99))
+            taps = None
+        else:
+            rate = float(rng.uniform(1.0, 6.0))
+            nt = int(rng.integers(40, 900))
+            taps = (np.hamming(nt) * np.sinc(np.linspace(-5, 5, nt))).astype(np.float32)
+        if taps is not None and rng.random() < 0.3:
+            taps = taps[: max(2, int(len(taps) * rng.uniform(0.02, 1.0)))].copy()      # short and even-length prototypes
+        n = int(rng.choice([1, 7, 300, 5000, 40_000, 90_001]))
+        x = noise(n, 1000 + case)
+        offset = 0.0 if rng.random() < 0.6 else float(rng.uniform(-0.5, 0.5))
+        sizes = [int(v) for v in rng.integers(1, max(2, n // 2 + 1), int(rng.integers(0, 6)))]
+        ref = oracle.PfbArbResampler(rate, taps)
+        xr = oracle.Rotator(2 * math.pi * offset).work(x) if offset else x
+        want = ref.work(xr)
+        ch = g.channelizer(2 * math.pi * offset, rate, ref.taps)
+        if rng.random() < 0.3:
+            ch.force_general(True)
+        got = np.concatenate([ch.work(c) for c in chunks_of(x, sizes)] + [np.zeros(0, np.complex64)])
+        what = f"case {case}: rate {rate:.4f} ntaps {len(ref.taps)} n {n} offset {offset:.3f} chunks {sizes} {ch.kernel_name}"
+        assert len(got) == len(want), what
+        if len(want) == 0:
+            ch.close()
+            continue
+        if offset == 0.0 and ch.kernel_name == "chan_general_kernel":
+            assert np.array_equal(got, want), what
+            exact += 1
+        elif offset == 0.0:
+            assert rel_max(got, want) <= 4e-6, what
+            close += 1
+        else:
+            scale = np.abs(want).max()
+            if len(want) >= 64 and scale > 0:
+                assert drift_and_residual(got, want, scale="max")[1] <= 5e-5, what
+            else:
+                assert np.abs(got - want).max() <= 5e-5 * max(scale, 1e-30), what
+            rotated += 1
+        ch.close()
+    print(f"{exact} exact, {close} within 4e-6, {rotated} rotated within 5e-5")
+    assert exact >= 20 and close >= 10 and rotated >= 20
