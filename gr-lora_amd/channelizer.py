@@ -57,11 +57,15 @@ class channelizer:
     dec_rate = property(lambda self: lib().lora_hip_chan_dec_rate(self._h))
     flt_rate = property(lambda self: lib().lora_hip_chan_flt_rate(self._h))
     kernel_name = property(lambda self: lib().lora_hip_chan_kernel_name(self._h).decode())
+    phase_inc_effective = property(lambda self: lib().lora_hip_chan_phase_inc_effective(self._h))
 
     def force_general(self, on=True):
         self._check(lib().lora_hip_chan_force_general(self._h, int(on)))
 
     def set_stream(self, stream_ptr):
+        """Run on a caller-owned hipStream_t; None/0 goes back to the default: the handle's own stream for host
+        arrays, torch's current stream for cuda tensors (so that work() is ordered after whatever produced them)."""
+        self._user_stream = bool(stream_ptr)
         self._check(lib().lora_hip_chan_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
     def reset(self):
@@ -78,6 +82,16 @@ class channelizer:
         n_out = self.output_count(n_in)
         if on_dev:
             import torch
+            if not getattr(self, "_user_stream", False):
+                cur = torch.cuda.current_stream(x.device)
+                if cur.cuda_stream:
+                    self._check(lib().lora_hip_chan_set_stream(self._h, C.c_void_p(cur.cuda_stream)))
+                else:
+                    # torch's default stream is the null stream, which the C ABI cannot name (NULL = the handle's own
+                    # stream): order by hand -- wait for the producer of x, run synchronously on the handle's stream
+                    cur.synchronize()
+                    self._check(lib().lora_hip_chan_set_stream(self._h, None))
+                    async_ = False
             if out is None:
                 out = torch.empty(max(n_out, 1), dtype=torch.complex64, device=x.device)
             assert out.is_cuda and out.is_contiguous() and x.is_contiguous() and out.numel() >= n_out
@@ -85,6 +99,8 @@ class channelizer:
             flags = capi.IQ_ON_DEVICE | capi.OUT_ON_DEVICE | (capi.ASYNC if async_ else 0)
         else:
             x = np.ascontiguousarray(x, np.complex64)
+            if not getattr(self, "_user_stream", False):
+                self._check(lib().lora_hip_chan_set_stream(self._h, None))
             if out is None:
                 out = np.empty(max(n_out, 1), np.complex64)
             pin, pout, cap, flags = x.ctypes.data, out.ctypes.data, len(out), 0

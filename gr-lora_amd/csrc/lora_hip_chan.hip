@@ -609,6 +609,7 @@ unsigned lora_hip_chan_taps_per_filter(const lora_hip_chan_t *h) { return h ? h-
 unsigned lora_hip_chan_dec_rate(const lora_hip_chan_t *h) { return h ? h->dec_rate : 0; }
 float lora_hip_chan_flt_rate(const lora_hip_chan_t *h) { return h ? h->flt_rate : 0.0f; }
 const char *lora_hip_chan_kernel_name(const lora_hip_chan_t *h) { return h ? h->kernel_name : ""; }
+double lora_hip_chan_phase_inc_effective(const lora_hip_chan_t *h) { return h ? h->inc_eff : 0.0; }
 
 int lora_hip_chan_reset(lora_hip_chan_t *h) {
   if (!h) return LORA_HIP_EINVAL;

@@ -62,6 +62,10 @@ LORA_HIP_API int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size
 LORA_HIP_API unsigned lora_hip_chan_taps_per_filter(const lora_hip_chan_t *h);
 LORA_HIP_API unsigned lora_hip_chan_dec_rate(const lora_hip_chan_t *h);     /* d_dec_rate */
 LORA_HIP_API float lora_hip_chan_flt_rate(const lora_hip_chan_t *h);        /* d_flt_rate */
+/* the rotation applied per sample, in radians: the angle of the reference's increment exp(i*(float)phase_inc)
+ * after rounding to complex<float> and normalising (rotator::set_phase_incr); differs from phase_inc by up to
+ * ~1e-7 rad, which is 6 rad over 64 M samples */
+LORA_HIP_API double lora_hip_chan_phase_inc_effective(const lora_hip_chan_t *h);
 /* name of the kernel work() dispatches to: "chan_decim_kernel<D,..>" for whole-number decimation (d_flt_rate
  * 0, d_dec_rate a multiple of nfilts), "chan_general_kernel" otherwise */
 LORA_HIP_API const char *lora_hip_chan_kernel_name(const lora_hip_chan_t *h);
