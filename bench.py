@@ -79,6 +79,36 @@ def cpu_baseline(capture, budget_s=12.0):
     return out
 
 
+def channeliser_leg(torch, g, dev, stream, total_bytes=1 << 30, reps=20):
+    """Beside the headline (never part of `value`): the channeliser in front of the block at the
+    reference flowgraph's setting -- 1 MS/s -> 250 kS/s, offset -250 kHz (examples/rx_usrp.grc:95,270,401) -- over
+    1 GiB of complex64 resident in HBM, timed with HIP events on the launch stream."""
+    import math
+    n = total_bytes // 8
+    x = torch.view_as_complex(torch.randn(n, 2, device=dev, dtype=torch.float32))
+    ch = g.channelizer(2 * math.pi * (-250e3) / 1e6, 250e3 / 1e6, device=dev.index or 0)
+    out = torch.empty(ch.output_count(n) + 8, dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    ch.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            ch.work(x, out=out, async_=True)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            y = ch.work(x, out=out, async_=True)
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 8 * (n + len(y)) / (ms * 1e-3) / 1e9
+    res = {"kernel": ch.kernel_name, "workload": "rate 0.25, offset -0.25 cycles/sample, 100 dB taps (91 per arm), 1 GiB in",
+           "kernel_ms": round(ms, 4), "input_gsamp_per_s": round(n / ms / 1e6, 1),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_input_sample": 8 + 8 * 0.25}}
+    ch.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +141,7 @@ def main():
     cap = synth.capture(SF, CAPTURE_SAMPLES, symbols_per_packet=64, seed=2 + rank)
     replicas = -(-MIN_RESIDENT_BYTES // (cap.nbytes))
     iq = torch.from_numpy(cap).to(dev).repeat(replicas)           # complex64, resident in HBM
+    torch.cuda.synchronize()                                      # built on torch's stream, read on `stream` below
     n_samples = iq.numel()
     count = n_samples // n                                        # stride-N windows per step
     out_idx = torch.empty(count, dtype=torch.int16, device=dev)
@@ -204,6 +235,11 @@ def main():
                          "device_copy_gbs": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                          "secondary": secondary},
         }
+        if world == 1:
+            try:
+                line["next_rows"] = {"channeliser": channeliser_leg(torch, g, dev, stream)}
+            except Exception as e:              # the headline line must not depend on this leg
+                line["next_rows"] = {"channeliser": {"error": str(e)[:200]}}
         if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cap)
         print(json.dumps(line), flush=True)

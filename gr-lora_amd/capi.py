@@ -25,6 +25,7 @@ EXPORTS = (
     "lora_hip_demod_create", "lora_hip_demod_destroy", "lora_hip_demod_set_stream", "lora_hip_demod_batch",
     "lora_hip_demod_batch_strided", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
     "lora_hip_demod_kernel_name", "lora_hip_demod_stage_iq", "lora_hip_demod_stage_iq2",
+    "lora_hip_demod_stage_iq2_dev", "lora_hip_demod_fetch", "lora_demod_core_work_device", "lora_demod_core_set_stream",
     # include/lora_demod_core.h
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
@@ -82,6 +83,10 @@ def lib():
     L.lora_hip_demod_kernel_name.argtypes = [vp]; L.lora_hip_demod_kernel_name.restype = C.c_char_p
     L.lora_hip_demod_stage_iq.argtypes = [vp, vp, sz]; L.lora_hip_demod_stage_iq.restype = i
     L.lora_hip_demod_stage_iq2.argtypes = [vp, vp, sz, vp, sz]; L.lora_hip_demod_stage_iq2.restype = i
+    L.lora_hip_demod_stage_iq2_dev.argtypes = [vp, vp, sz, vp, sz]; L.lora_hip_demod_stage_iq2_dev.restype = i
+    L.lora_hip_demod_fetch.argtypes = [vp, vp, sz, vp]; L.lora_hip_demod_fetch.restype = i
+    L.lora_demod_core_work_device.argtypes = [vp, vp, sz, PDU_CB, vp]; L.lora_demod_core_work_device.restype = i
+    L.lora_demod_core_set_stream.argtypes = [vp, vp]; L.lora_demod_core_set_stream.restype = i
     L.lora_demod_core_create.argtypes = [C.POINTER(vp), i, u, i, f, u]; L.lora_demod_core_create.restype = i
     L.lora_demod_core_destroy.argtypes = [vp]; L.lora_demod_core_destroy.restype = None
     L.lora_demod_core_work.argtypes = [vp, vp, sz, PDU_CB, vp]; L.lora_demod_core_work.restype = i

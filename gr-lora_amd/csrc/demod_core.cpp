@@ -72,6 +72,10 @@ struct lora_demod_core {
   // host: only the GPU reads samples, the host keeps what a later call may still need; pos = read index
   std::vector<lora_c32> buf;
   const lora_c32 *cur_in = nullptr; size_t cur_n = 0;
+  // device-resident input (lora_demod_core_work_device): cur_in is a device pointer; only the carry and the first
+  // head_n input samples are staged (windows that start inside the carry end there), every other window is read
+  // from cur_in where it lies
+  bool cur_dev = false; size_t head_n = 0;
   size_t total() const { return buf.size() + cur_n; }
   uint64_t base = 0, pos = 0;
   // GPU result caches
@@ -97,7 +101,15 @@ int fail(lora_demod_core *c, int rc, const char *what) {
 
 int ensure_staged(lora_demod_core *c) {
   if (c->staged) return LORA_HIP_OK;
-  int rc = lora_hip_demod_stage_iq2(c->hip, c->buf.data(), c->buf.size(), c->cur_in, c->cur_n);
+  int rc;
+  if (c->cur_dev) {
+    // a window that starts inside the carry (< 4N samples) ends at most N samples into the input
+    const size_t head_cap = (size_t)(DEMOD_HISTORY_DEPTH + 1) * c->d_num_symbols;
+    c->head_n = c->cur_n < head_cap ? c->cur_n : head_cap;
+    rc = lora_hip_demod_stage_iq2_dev(c->hip, c->buf.data(), c->buf.size(), c->cur_in, c->head_n);
+  } else {
+    rc = lora_hip_demod_stage_iq2(c->hip, c->buf.data(), c->buf.size(), c->cur_in, c->cur_n);
+  }
   if (rc) return fail(c, rc, "stage_iq");
   c->staged = true;
   return LORA_HIP_OK;
@@ -109,10 +121,38 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
   if (rc) return rc;
   r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
   r.idx.assign(count, 0); r.val.assign(count, 0.f);
-  rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->total(), start - c->base, stride, count, off0, off_step,
-                                    kind, r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+  const uint64_t s0 = start - c->base;
+  if (!c->cur_dev || c->head_n == c->cur_n) {
+    // everything the windows touch is in the staging buffer
+    rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->total(), s0, stride, count, off0, off_step,
+                                      kind, r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+    c->n_launches++;
+  } else {
+    // device-resident input: the windows that start inside the carry come from the staged head, all others
+    // from the caller's buffer in place
+    const uint64_t carry = c->buf.size();
+    size_t k0 = 0;
+    if (s0 < carry) {
+      const uint64_t k = (carry - s0 + stride - 1) / stride;
+      k0 = k < count ? (size_t)k : count;
+    }
+    rc = LORA_HIP_OK;
+    if (k0) {
+      rc = lora_hip_demod_batch_strided(c->hip, nullptr, carry + c->head_n, s0, stride, k0, off0, off_step, kind,
+                                        r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+      c->n_launches++;
+    }
+    if (!rc && count > k0) {
+      const unsigned n = c->d_num_symbols;
+      const unsigned off_k0 = (unsigned)((off0 + (uint64_t)k0 * off_step) & (n - 1));
+      rc = lora_hip_demod_batch_strided(c->hip, c->cur_in, c->cur_n, s0 + (uint64_t)k0 * stride - carry, stride,
+                                        count - k0, off_k0, off_step, kind, r.idx.data() + k0, r.val.data() + k0,
+                                        LORA_HIP_IQ_ON_DEVICE);
+      c->n_launches++;
+    }
+  }
   if (rc) { r.idx.clear(); r.val.clear(); return fail(c, rc, "batch_strided"); }
-  c->n_windows += count; c->n_launches++;
+  c->n_windows += count;
   return LORA_HIP_OK;
 }
 
@@ -321,9 +361,24 @@ void lora_demod_core_destroy(lora_demod_core_t *c) {
   delete c;
 }
 
+static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool on_device, lora_pdu_cb cb, void *user);
+
 int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, lora_pdu_cb cb, void *user) {
+  return core_work(c, in, n_in, false, cb, user);
+}
+
+int lora_demod_core_work_device(lora_demod_core_t *c, const lora_c32 *in_device, size_t n_in, lora_pdu_cb cb, void *user) {
+  return core_work(c, in_device, n_in, true, cb, user);
+}
+
+int lora_demod_core_set_stream(lora_demod_core_t *c, void *hip_stream) {
+  if (!c) return LORA_HIP_EINVAL;
+  return lora_hip_demod_set_stream(c->hip, hip_stream);
+}
+
+static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool on_device, lora_pdu_cb cb, void *user) {
   if (!c || (!in && n_in)) return LORA_HIP_EINVAL;
-  c->cur_in = in; c->cur_n = n_in;
+  c->cur_in = in; c->cur_n = n_in; c->cur_dev = on_device && n_in; c->head_n = 0;
   if (n_in) c->staged = false;
   const uint64_t need = (uint64_t)c->d_num_symbols + (uint64_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1;
   int rc = LORA_HIP_OK;
@@ -340,14 +395,28 @@ int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, 
       c->buf.erase(c->buf.begin(), c->buf.begin() + (size_t)(c->pos - c->base));
     } else if (c->pos >= carry_end) {
       const size_t skip = (size_t)(c->pos - carry_end);             // pos <= end: a call never consumes past need
-      c->buf.assign(in + (skip < n_in ? skip : n_in), in + n_in);
+      const size_t from = skip < n_in ? skip : n_in;
+      if (c->cur_dev) {                                             // the unconsumed tail (< 4N samples) comes back from HBM
+        c->buf.resize(n_in - from);
+        const int rf = lora_hip_demod_fetch(c->hip, in + from, n_in - from, c->buf.data());
+        if (rf) rc = rc ? rc : fail(c, rf, "fetch");
+      } else {
+        c->buf.assign(in + from, in + n_in);
+      }
     } else {
       c->buf.erase(c->buf.begin(), c->buf.begin() + (size_t)(c->pos - c->base));
-      c->buf.insert(c->buf.end(), in, in + n_in);
+      if (c->cur_dev) {                                             // fewer than 4N new samples: all of them are kept
+        const size_t old = c->buf.size();
+        c->buf.resize(old + n_in);
+        const int rf = lora_hip_demod_fetch(c->hip, in, n_in, c->buf.data() + old);
+        if (rf) rc = rc ? rc : fail(c, rf, "fetch");
+      } else {
+        c->buf.insert(c->buf.end(), in, in + n_in);
+      }
     }
   } catch (const std::bad_alloc &) { rc = rc ? rc : LORA_HIP_ENOMEM; }
   c->base = c->pos > c->base ? c->pos : c->base;
-  c->cur_in = nullptr; c->cur_n = 0;
+  c->cur_in = nullptr; c->cur_n = 0; c->cur_dev = false; c->head_n = 0;
   c->staged = false;
   if (rc) return rc;
   return LORA_HIP_OK;

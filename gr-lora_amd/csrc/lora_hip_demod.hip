@@ -351,6 +351,31 @@ int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a,
   return LORA_HIP_OK;
 }
 
+int lora_hip_demod_stage_iq2_dev(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a, const lora_c32 *b_dev, size_t n_b) {
+  if (!h || (!a && n_a) || (!b_dev && n_b)) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  h->staged_n = 0;
+  const size_t n = n_a + n_b;
+  int rc = grow(h, &h->d_iq, &h->cap_iq, n ? n : 1);
+  if (rc != LORA_HIP_OK) return rc;
+  if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (n_b) HIP_TRY(h, hipMemcpyAsync(h->d_iq + n_a, b_dev, n_b * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->staged_n = n;
+  return LORA_HIP_OK;
+}
+
+int lora_hip_demod_fetch(lora_hip_demod_t *h, const lora_c32 *src_dev, size_t n, lora_c32 *dst) {
+  if (!h || (n && (!src_dev || !dst))) return LORA_HIP_EINVAL;
+  if (!n) return LORA_HIP_OK;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  HIP_TRY(h, hipMemcpyAsync(dst, src_dev, n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return LORA_HIP_OK;
+}
+
 int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples) {
   return lora_hip_demod_stage_iq2(h, iq, n_samples, nullptr, 0);
 }

@@ -94,9 +94,23 @@ class demod:
             raise capi.LoraHipError(rc)
 
     def work(self, samples):
-        """Feed complex64 samples; returns the PDUs completed by this call as u16 arrays."""
-        x = np.ascontiguousarray(samples, np.complex64)
+        """Feed complex64 samples; returns the PDUs completed by this call as u16 arrays.  A torch cuda tensor
+        (e.g. the channeliser's output) is read where it lies in HBM (lora_demod_core_work_device)."""
         self._pending = []
+        if capi._is_torch(samples) and samples.is_cuda:
+            import torch
+            assert samples.dtype == torch.complex64 and samples.is_contiguous()
+            cur = torch.cuda.current_stream(samples.device)
+            if cur.cuda_stream:
+                capi.lib().lora_demod_core_set_stream(self._h, C.c_void_p(cur.cuda_stream))
+            else:       # torch's default stream is the null stream, which the C ABI cannot name: wait for the producer
+                cur.synchronize()
+                capi.lib().lora_demod_core_set_stream(self._h, None)
+            rc = capi.lib().lora_demod_core_work_device(self._h, samples.data_ptr(), samples.numel(), self._cb, None)
+            if rc:
+                raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
+            return [p[1] for p in self._pending]
+        x = np.ascontiguousarray(samples, np.complex64)
         rc = capi.lib().lora_demod_core_work(self._h, x.ctypes.data, len(x), self._cb, None)
         if rc:
             raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())

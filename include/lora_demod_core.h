@@ -62,6 +62,16 @@ LORA_HIP_API int lora_demod_core_reset(lora_demod_core_t *c);
 LORA_HIP_API int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in,
                                       lora_pdu_cb cb, void *user);
 
+/* The same for samples that are already in HBM of the block's GPU (a device pointer), e.g. the output of the
+ * channeliser (lora_hip_chan.h): the windows are read where they lie, nothing goes through the host except the
+ * (argmax, max) pairs and the < 4N samples of history a call sequence leaves unconsumed.  No counterpart in the
+ * reference (its input buffer is the scheduler's host memory, :155).  The samples must be complete when the
+ * call is made, or be produced on the stream given to lora_demod_core_set_stream. */
+LORA_HIP_API int lora_demod_core_work_device(lora_demod_core_t *c, const lora_c32 *in_device, size_t n_in,
+                                             lora_pdu_cb cb, void *user);
+/* Run the block's GPU work on a caller-owned hipStream_t (void*); NULL restores the block's own stream. */
+LORA_HIP_API int lora_demod_core_set_stream(lora_demod_core_t *c, void *hip_stream);
+
 /* Time-segment sharding of one long capture (design A; no counterpart in the
  * reference, which is one sequential thread per channel).  Outside READ_HEADER / READ_PAYLOAD the
  * up-path result of a call (lib/demod_impl.cc:177-206 with downchirp offset 0) depends only on its

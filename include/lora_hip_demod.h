@@ -131,6 +131,14 @@ LORA_HIP_API int lora_hip_demod_stage_iq(lora_hip_demod_t *h, const lora_c32 *iq
 LORA_HIP_API int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a,
                                           const lora_c32 *b, size_t n_b);
 
+/* The same with the second piece already in HBM (a device pointer on the handle's GPU): a host-side history in
+ * front of samples that an upstream GPU stage (the channeliser, lora_hip_chan.h) produced. */
+LORA_HIP_API int lora_hip_demod_stage_iq2_dev(lora_hip_demod_t *h, const lora_c32 *a_host, size_t n_a,
+                                              const lora_c32 *b_device, size_t n_b);
+/* Copy n samples from HBM to host memory on the handle's stream and wait for them: how a host-side block
+ * keeps the few unconsumed samples of a device-resident input as its history (set_history, :103). */
+LORA_HIP_API int lora_hip_demod_fetch(lora_hip_demod_t *h, const lora_c32 *src_device, size_t n, lora_c32 *dst_host);
+
 /* geometry of the handle */
 LORA_HIP_API unsigned lora_hip_demod_sf(const lora_hip_demod_t *h);
 LORA_HIP_API unsigned lora_hip_demod_fft_factor(const lora_hip_demod_t *h);
