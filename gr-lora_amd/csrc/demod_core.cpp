@@ -81,7 +81,8 @@ struct lora_demod_core {
   // GPU result caches
   std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
   std::vector<Run> pre_runs;     // handed in through lora_demod_core_preload
-  Run sfd_run;
+  std::vector<Run> sfd_runs;     // one per detect-lattice phase that has needed a sweep, bounded (16 phases)
+  unsigned sfd_misses[OVERLAP_FACTOR] = {0};
   bool staged = false;
   // instrumentation
   lora_core_trace *trace = nullptr; size_t max_trace = 0;
@@ -192,21 +193,39 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
   return LORA_HIP_OK;
 }
 
-// argmax of one overlapped SFD window: lib/demod_impl.cc:297-322
+// argmax of one overlapped SFD window: lib/demod_impl.cc:297-322.
+// The window at absolute position p of a sync attempt whose calls sit on the detect lattice of phase
+// phi = call_pos mod N uses the chirp offset (p - phi) mod N (:297, d_offset = ol*N/16 and read indices move by N
+// between the calls of one attempt): its result depends on (p, phi) only, not on which call or attempt asks.  One
+// stride-N/16 sweep therefore serves every later attempt on the same lattice phase.  The first sweep of a phase
+// covers one attempt (at most 10 calls x 16 windows, :283-292); when the same phase needs a second one, packets
+// keep arriving on it, and the sweep runs far ahead: a window costs the GPU nanoseconds, a launch and its
+// synchronisation tens of microseconds (dense traffic: one launch per packet before, 386 -> 32 launches).
 int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx) {
   const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
   size_t k;
-  if (!c->sfd_run.find(call_pos + off, off, n, &k)) {
-    // cover the rest of this call and the following calls of the sync attempt
-    const uint64_t end = c->base + c->total();
-    const uint64_t first = call_pos + off;
-    size_t avail = (size_t)((end - first - n) / step + 1);
-    size_t want = (size_t)OVERLAP_FACTOR * 10 + OVERLAP_FACTOR;
-    int rc = launch_run(c, c->sfd_run, first, step, avail < want ? avail : want, off, step, LORA_WIN_SFD);
-    if (rc) return rc;
-    k = 0;
+  for (size_t r = c->sfd_runs.size(); r-- > 0;) {
+    if (c->sfd_runs[r].find(call_pos + off, off, n, &k)) { *idx = c->sfd_runs[r].idx[k]; return LORA_HIP_OK; }
   }
-  *idx = c->sfd_run.idx[k];
+  // miss: drop sweeps that lie entirely behind the read index
+  for (size_t r = 0; r < c->sfd_runs.size();) {
+    const Run &u = c->sfd_runs[r];
+    if (u.start + (uint64_t)u.idx.size() * u.stride <= c->pos) c->sfd_runs.erase(c->sfd_runs.begin() + r);
+    else r++;
+  }
+  if (c->sfd_runs.size() >= 2 * OVERLAP_FACTOR) c->sfd_runs.erase(c->sfd_runs.begin());
+  const uint64_t end = c->base + c->total();
+  const uint64_t first = call_pos + off;
+  const size_t avail = (size_t)((end - first - n) / step + 1);
+  const unsigned phase = (unsigned)((call_pos % n) / step);
+  const size_t one_attempt = (size_t)OVERLAP_FACTOR * 10 + OVERLAP_FACTOR;
+  // far ahead = about 0.3 ms of GPU work whatever the spreading factor (a window costs ~N/400 ns)
+  const size_t far_ahead = ((size_t)1 << 27) >> c->d_sf < ((size_t)1 << 17) ? ((size_t)1 << 27) >> c->d_sf : ((size_t)1 << 17);
+  const size_t want = (++c->sfd_misses[phase] >= 2) ? far_ahead : one_attempt;
+  c->sfd_runs.emplace_back();
+  int rc = launch_run(c, c->sfd_runs.back(), first, step, avail < want ? avail : want, off, step, LORA_WIN_SFD);
+  if (rc) { c->sfd_runs.pop_back(); return rc; }
+  *idx = c->sfd_runs.back().idx[0];
   return LORA_HIP_OK;
 }
 
@@ -348,7 +367,8 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
   c->cur_in = nullptr; c->cur_n = 0;
   c->base = 0; c->pos = 0;
-  c->up_runs.clear(); c->pre_runs.clear(); c->sfd_run = Run();
+  c->up_runs.clear(); c->pre_runs.clear(); c->sfd_runs.clear();
+  for (unsigned &m : c->sfd_misses) m = 0;
   c->staged = false;
   c->n_calls = 0; c->n_windows = 0; c->n_launches = 0;
   c->err.clear();
