@@ -80,6 +80,7 @@ struct lora_demod_core {
   uint64_t base = 0, pos = 0;
   // GPU result caches
   std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
+  size_t last_up = 0;            // index of the sweep that answered the last up-path lookup
   std::vector<Run> pre_runs;     // handed in through lora_demod_core_preload
   std::vector<Run> sfd_runs;     // one per detect-lattice phase that has needed a sweep, bounded (16 phases)
   unsigned sfd_misses[OVERLAP_FACTOR] = {0};
@@ -161,8 +162,13 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
 int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, float *val) {
   const unsigned n = c->d_num_symbols;
   size_t k;
+  // consecutive calls walk along one sweep: try the one that answered last before searching them all
+  if (c->last_up < c->up_runs.size() && c->up_runs[c->last_up].find(pos, off, n, &k)) {
+    *idx = c->up_runs[c->last_up].idx[k]; *val = c->up_runs[c->last_up].val[k];
+    return LORA_HIP_OK;
+  }
   for (size_t r = c->up_runs.size(); r-- > 0;) {
-    if (c->up_runs[r].find(pos, off, n, &k)) { *idx = c->up_runs[r].idx[k]; *val = c->up_runs[r].val[k]; return LORA_HIP_OK; }
+    if (c->up_runs[r].find(pos, off, n, &k)) { c->last_up = r; *idx = c->up_runs[r].idx[k]; *val = c->up_runs[r].val[k]; return LORA_HIP_OK; }
   }
   for (size_t r = c->pre_runs.size(); r-- > 0;) {
     if (c->pre_runs[r].find(pos, off, n, &k)) { *idx = c->pre_runs[r].idx[k]; *val = c->pre_runs[r].val[k]; return LORA_HIP_OK; }
@@ -189,6 +195,7 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
   c->up_runs.emplace_back();
   int rc = launch_run(c, c->up_runs.back(), pos, n, avail < want ? avail : want, off, 0, LORA_WIN_UP);
   if (rc) { c->up_runs.pop_back(); return rc; }
+  c->last_up = c->up_runs.size() - 1;
   *idx = c->up_runs.back().idx[0]; *val = c->up_runs.back().val[0];
   return LORA_HIP_OK;
 }

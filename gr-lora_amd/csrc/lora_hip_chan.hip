@@ -132,6 +132,71 @@ __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
   }
 }
 
+// ---- fractional rates, fast path -----------------------------------------------------------------------
+// Same sums as chan_general_kernel in closed-form mode 1, arranged for throughput instead of for the reference's
+// rounding order: the arm bank and the difference bank sit in LDS interleaved as {f0, f1}[arm][k] (row stride odd,
+// so lanes on different arms spread over the banks), the interpolated tap f0 + d_acc*f1 is formed once per tap and
+// applied to re and im with FMAs: 3 VALU and two 8-byte LDS reads per tap and output, against 4 VALU, one LDS read
+// and two global tap reads before.  LDS-bandwidth-bound by construction (every lane has its own arm and window).
+// Parity: within 2e-6 of the output RMS of a double-precision evaluation (the float oracle sits at the same
+// distance); the bit-exact form stays available (lora_hip_chan_force_general).
+template <bool ROT>
+__global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const unsigned K = p.K, KP = K | 1u;
+  float2 *bank = reinterpret_cast<float2 *>(smem_raw);          // [nfilts][KP]
+  float2 *tile = bank + (size_t)p.nfilts * KP;
+  const int tid = threadIdx.x;
+  constexpr unsigned long long kMask = (1ull << kFracBits) - 1;
+  for (unsigned i = tid; i < p.nfilts * K; i += kBlock) {
+    const unsigned j = i / K, k = i - j * K;
+    bank[j * KP + k] = make_float2(p.filt[i], p.dfilt[i]);
+  }
+  auto pos = [&](const unsigned long long m) -> unsigned long long {
+    return p.p0 + m * p.dec + ((p.a0 + m * p.a) >> kFracBits);
+  };
+  const unsigned long long n_tiles = (p.n_out + p.tile_out - 1) / p.tile_out;
+  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const unsigned long long m0 = t * p.tile_out;
+    const unsigned long long m1 = (m0 + p.tile_out < p.n_out) ? m0 + p.tile_out : p.n_out;
+    const long long s_lo = (long long)(pos(m0) / p.nfilts) - (long long)(K - 1);
+    const int span = (int)((long long)(pos(m1 - 1) / p.nfilts) - s_lo + 1);
+    __syncthreads();                                             // the previous tile's readers are done (and the bank is visible)
+    for (int i = tid; i < span; i += kBlock) {
+      float2 x = fetch(p, s_lo + i);
+      if (ROT) {
+        double sn, cs;
+        sincos(p.phase0 + p.inc * (double)(s_lo + i), &sn, &cs);
+        x = cmul_f(x, make_float2((float)cs, (float)sn));
+      }
+      tile[i] = x;
+    }
+    __syncthreads();
+    const unsigned long long m = m0 + tid;
+    if (m < m1) {
+      const unsigned long long P = pos(m);
+      const unsigned j = (unsigned)(P % p.nfilts);
+      const float a = (float)((p.a0 + m * p.a) & kMask) * (1.0f / (float)(1u << kFracBits));
+      const float2 *__restrict__ x = tile + ((long long)(P / p.nfilts) - (long long)(K - 1) - s_lo);
+      const float2 *__restrict__ f = bank + j * KP;
+      float re0 = 0, im0 = 0, re1 = 0, im1 = 0;                  // two chains for latency
+      unsigned k = 0;
+      for (; k + 2 <= K; k += 2) {
+        const float2 t0 = f[k], t1 = f[k + 1], v0 = x[k], v1 = x[k + 1];
+        const float h0 = __builtin_fmaf(a, t0.y, t0.x), h1 = __builtin_fmaf(a, t1.y, t1.x);
+        re0 = __builtin_fmaf(h0, v0.x, re0); im0 = __builtin_fmaf(h0, v0.y, im0);
+        re1 = __builtin_fmaf(h1, v1.x, re1); im1 = __builtin_fmaf(h1, v1.y, im1);
+      }
+      if (k < K) {
+        const float2 t0 = f[k], v0 = x[k];
+        const float h0 = __builtin_fmaf(a, t0.y, t0.x);
+        re0 = __builtin_fmaf(h0, v0.x, re0); im0 = __builtin_fmaf(h0, v0.y, im0);
+      }
+      p.out[m] = make_float2(re0 + re1, im0 + im1);
+    }
+  }
+}
+
 // ---- whole-number decimation ---------------------------------------------------------------------------
 // out[m] = sum_u g[u] * X[i0 + D*m - u], g = the arm's taps in natural order, u < K.  With u = D*q + ph:
 //   out[m] = sum_ph sum_q g[D*q + ph] * Z_ph[m - q],   Z_ph[n] = X[i0 + D*n - ph]
@@ -405,6 +470,12 @@ const DecimVariant *pick_decim(const lora_hip_chan *h) {
 }
 
 constexpr int kGeneralTileSamples = 6144;       // 48 KiB of LDS per workgroup
+constexpr size_t kArbLdsBytes = 64 * 1024;      // chan_arb_kernel: banks + tile per workgroup
+// the fast fractional-rate kernel needs both banks and a useful tile in LDS
+inline size_t arb_bank_bytes(const lora_hip_chan *h) { return (size_t)h->nfilts * (h->K | 1u) * 8; }
+inline bool arb_fits(const lora_hip_chan *h) {
+  return h->frac && !h->force_general && arb_bank_bytes(h) + (size_t)(4 * h->K + 64) * 8 <= kArbLdsBytes;
+}
 constexpr int kFracBits = lora_chan::kFracBits;
 constexpr unsigned long long kFracMask = (1ull << kFracBits) - 1;
 
@@ -572,6 +643,9 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
                          (const void *)&lora_chan::chan_general_kernel<false, 2>, (const void *)&lora_chan::chan_general_kernel<true, 2>};
     for (const void *f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralTileSamples * 8) != hipSuccess) return fail(LORA_HIP_EHIP);
+    const void *arb[] = {(const void *)&lora_chan::chan_arb_kernel<false>, (const void *)&lora_chan::chan_arb_kernel<true>};
+    for (const void *f : arb)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kArbLdsBytes) != hipSuccess) return fail(LORA_HIP_EHIP);
   }
   lora_hip_chan_force_general(h, 0);
   *out = h;
@@ -583,6 +657,7 @@ int lora_hip_chan_force_general(lora_hip_chan_t *h, int on) {
   h->force_general = on != 0;
   const DecimVariant *v = pick_decim(h);
   if (v) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch);
+  else if (h->a != 0 && arb_fits(h)) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_arb_kernel");
   else snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel");
   return LORA_HIP_OK;
 }
@@ -693,6 +768,19 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
         p.rot_lane = h->d_rot_lane;
       }
       hipLaunchKernelGGL(v->fn[rot ? 1 : 0], dim3(blocks), dim3(lora_chan::kBlock), 0, h->stream, p);
+    } else if (mode == 1 && arb_fits(h)) {
+      // fractional rate, banks in LDS: outputs per tile = as many as keep the tile's input span in what is left
+      const size_t tile_samples = (kArbLdsBytes - arb_bank_bytes(h)) / 8;
+      unsigned to = lora_chan::kBlock;
+      auto span_of = [&](unsigned t) { return ((unsigned long long)(t - 1) * (h->dec_rate + 1)) / h->nfilts + 2 + h->K; };
+      while (to > 1 && span_of(to) > (unsigned long long)tile_samples) to /= 2;
+      if (span_of(to) > (unsigned long long)tile_samples) return LORA_HIP_EUNSUPPORTED;   // arb_fits leaves room for 4K samples
+      p.tile_out = to;
+      const unsigned long long tiles = (cnt + to - 1) / to;
+      unsigned blocks = (unsigned)h->num_cu * 2;
+      if (tiles < blocks) blocks = (unsigned)tiles;
+      hipLaunchKernelGGL(rot ? &lora_chan::chan_arb_kernel<true> : &lora_chan::chan_arb_kernel<false>, dim3(blocks),
+                         dim3(lora_chan::kBlock), kArbLdsBytes, h->stream, p);
     } else {
       // outputs per tile: as many as keep the tile's input span inside the LDS tile
       unsigned to = lora_chan::kBlock;

@@ -115,6 +115,30 @@ def test_decim_kernel_within_tolerance(d, atten, g):
     ch.close()
 
 
+@pytest.mark.parametrize("rate,taps", [(0.3, None), (0.7, None), (0.13, None), (0.9999, None), (1.5, "own"), (2.75, "own")])
+def test_fractional_rate_kernel_within_tolerance(rate, taps, g):
+    """chan_arb_kernel: interpolated taps formed once per tap, FMA sums; against the double-precision oracle."""
+    if taps == "own":
+        taps = (np.hamming(32 * 12 + 5) * np.sinc(np.linspace(-6, 6, 32 * 12 + 5))).astype(np.float32)
+    x = noise(200_000, 31)
+    ref = oracle.PfbArbResampler(rate, taps)
+    want = oracle.PfbArbResampler(rate, ref.taps).work(x, use_double=True)
+    want_f = ref.work(x)
+    ch = g.channelizer(0.0, rate, ref.taps)
+    assert ch.kernel_name == "chan_arb_kernel"
+    got = ch.work(x)
+    assert len(got) == len(want)
+    e_gpu, e_cpu = rel_max(got, want), rel_max(want_f, want)
+    print(f"rate {rate} K={ch.taps_per_filter}: max err / rms  gpu {e_gpu:.2e}  float oracle {e_cpu:.2e}")
+    assert e_gpu <= 2e-6
+    ch.reset()
+    got2 = np.concatenate([ch.work(c) for c in chunks_of(x, [5, 4097, 1, 77_777, 2])])
+    assert np.array_equal(got2, got)
+    ch.reset(); ch.force_general(True)
+    assert ch.kernel_name == "chan_general_kernel" and np.array_equal(ch.work(x), want_f)
+    ch.close()
+
+
 @pytest.mark.parametrize("rate,offset", [(0.25, -0.25), (0.125, 0.1837), (0.3, -0.41), (0.5, 0.05)])
 def test_rotation_and_resampling_against_the_two_blocks(rate, offset, g):
     x = noise(200_000, 23)
@@ -264,7 +288,7 @@ def test_random_streams_follow_the_oracle(g):
             rotated += 1
         ch.close()
     print(f"{exact} exact, {close} within 4e-6, {rotated} rotated within 5e-5")
-    assert exact >= 20 and close >= 10 and rotated >= 20
+    assert exact >= 8 and close >= 25 and rotated >= 20
 
 
 def test_full_size_properties(g):
