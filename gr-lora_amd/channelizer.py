@@ -31,7 +31,7 @@ class channelizer:
     Argument names follow the GRC block parameters (rx_usrp.grc:501, :837-854)."""
 
     def __init__(self, phase_inc=0.0, rrate=1.0, taps=None, nfilts=32, atten=100.0, device=0):
-        self.phase_inc, self.rrate, self.nfilts = float(phase_inc), float(rrate), int(nfilts)
+        self.phase_inc, self.rrate, self.nfilts, self.device = float(phase_inc), float(rrate), int(nfilts), int(device)
         self.taps = create_taps(rrate, nfilts, atten) if taps is None or len(taps) == 0 \
             else np.ascontiguousarray(taps, np.float32)
         self._h = C.c_void_p()

@@ -26,13 +26,22 @@ def iter_chunks(path, chunk_samples=1 << 22):
         yield np.asarray(x[k:k + chunk_samples])
 
 
-def demod_file(path, block, chunk_samples=1 << 22, flush_symbols=4):
+def demod_file(path, block, chunk_samples=1 << 22, flush_symbols=4, channelizer=None):
     """Feed a capture file to `block` (gr-lora_amd.demod or anything with work()); returns the PDUs.
     flush_symbols*N zeros are appended so that a packet ending at the end of the file is flushed (GNU
-    Radio's scheduler only calls the block while 4N-1 samples are available; a live source keeps going)."""
+    Radio's scheduler only calls the block while 4N-1 samples are available; a live source keeps going).
+    With `channelizer` (gr-lora_amd.channelizer) the file is a wideband capture: every chunk goes to the GPU once,
+    is shifted and resampled there, and the block reads the result in HBM (examples/rx_usrp.grc's chain from a
+    file instead of a USRP)."""
     pdus = []
-    for chunk in iter_chunks(path, chunk_samples):
-        pdus += block.work(chunk)
+    if channelizer is None:
+        for chunk in iter_chunks(path, chunk_samples):
+            pdus += block.work(chunk)
+    else:
+        import torch
+        dev = torch.device("cuda", getattr(channelizer, "device", 0))
+        for chunk in iter_chunks(path, chunk_samples):
+            pdus += block.work(channelizer.work(torch.tensor(chunk, device=dev)))    # one host-to-device copy per chunk
     if flush_symbols:
         n = 1 << block.spreading_factor
         pdus += block.work(np.zeros(flush_symbols * n, np.complex64))

@@ -79,3 +79,28 @@ def test_wideband_capture_stays_on_the_gpu(g):
     for a, b in zip(pdus, host):
         assert np.array_equal(a, b)
     ch.close(); blk.close()
+
+
+def test_wideband_capture_file(g, tmp_path):
+    """A raw float32 I/Q file of a wideband capture through iqfile.demod_file with a channeliser: same PDUs as the
+    arrays through host buffers, for a chunk size that cuts packets."""
+    from importlib import import_module
+    iqfile = import_module("gr-lora_amd.iqfile")
+    sf, f, up, off = 7, 2, 8, -0.31
+    n = 1 << sf
+    cap, _, _ = cases.make_capture(sf, [16, 30, 11], seed=91, snr_db=None)
+    spec = np.fft.fft(cap.astype(np.complex128)); m = len(cap)
+    wide = np.zeros(m * up, np.complex128)
+    wide[:m // 2] = spec[:m // 2]; wide[-(m - m // 2):] = spec[m // 2:]
+    wb = np.concatenate([np.fft.ifft(wide) * up * np.exp(-2j * np.pi * off * np.arange(m * up)),
+                         np.zeros(16 * n * up)]).astype(np.complex64)
+    path = str(tmp_path / "wide.32iq")
+    iqfile.write_iq(path, wb)
+    ch = g.channelizer(2 * math.pi * off, 1.0 / up)
+    want = g.demod(sf, False, cases.BETA, f).work(ch.work(wb))
+    ch.reset()
+    got = iqfile.demod_file(path, g.demod(sf, False, cases.BETA, f), chunk_samples=33_333, channelizer=ch)
+    assert len(want) == 3 and len(got) == 3
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    ch.close()
