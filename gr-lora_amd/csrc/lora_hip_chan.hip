@@ -11,10 +11,10 @@
 //     chan_decim_kernel splits it into its D polyphase components, one lane per component, 16 consecutive
 //     outputs per lane in registers, every LDS value used for up to 16 multiply-adds, then a DPP sum over
 //     the D lanes;
-//   * any other rate runs chan_general_kernel: one output per lane, arm and interpolation weight per output
-//     from the reference's recurrence (computed by the host: it is data-independent), taps applied in the
-//     reference's order with separately rounded products, so it is bit-identical to a sequential float
-//     evaluation when the rotation is off.
+//   * any other rate runs chan_arb_kernel (filter banks in LDS) or chan_general_kernel (banks too big for LDS):
+//     one output per lane, arm and interpolation weight per output from the closed form of the reference's
+//     recurrence, taps applied in the reference's order with separately rounded products, so both are
+//     bit-identical to a sequential float evaluation when the rotation is off.
 #include "lora_hip_chan.h"
 
 #include <hip/hip_runtime.h>
@@ -132,15 +132,15 @@ __global__ __launch_bounds__(kBlock) void chan_general_kernel(const CParams p) {
   }
 }
 
-// ---- fractional rates, fast path -----------------------------------------------------------------------
-// Same sums as chan_general_kernel in closed-form mode 1, arranged for throughput instead of for the reference's
-// rounding order: the arm bank and the difference bank sit in LDS interleaved as {f0, f1}[arm][k] (row stride odd,
-// so lanes on different arms spread over the banks), the interpolated tap f0 + d_acc*f1 is formed once per tap and
-// applied to re and im with FMAs: 3 VALU and two 8-byte LDS reads per tap and output, against 4 VALU, one LDS read
-// and two global tap reads before.  LDS-bandwidth-bound by construction (every lane has its own arm and window).
-// Parity: within 2e-6 of the output RMS of a double-precision evaluation (the float oracle sits at the same
-// distance); the bit-exact form stays available (lora_hip_chan_force_general).
-template <bool ROT>
+// ---- any rate whose filter banks fit LDS ------------------------------------------------------------------
+// The same sums as chan_general_kernel in the same order (separately rounded products, sequential float
+// accumulation, o0 + o1*d_acc), so the result is bit-identical to it and to the oracle's float evaluation; the
+// difference is where the taps come from: the arm bank and the difference bank sit in LDS interleaved as
+// {f0, f1}[arm][k] (row stride odd, so lanes on different arms spread over the banks) instead of being gathered
+// from global memory per lane.  Two 8-byte LDS reads per tap and output and nothing shared between lanes (every
+// lane has its own arm and its own window): LDS-bandwidth-bound by construction.
+// INTERP false: d_flt_rate == 0 (d_acc stays 0, the difference filter is not evaluated, as in mode 0 there).
+template <bool ROT, bool INTERP>
 __global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const unsigned K = p.K, KP = K | 1u;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
       if (ROT) {
         double sn, cs;
         sincos(p.phase0 + p.inc * (double)(s_lo + i), &sn, &cs);
-        x = cmul_f(x, make_float2((float)cs, (float)sn));
+        x = rotate(x, make_float2((float)cs, (float)sn));
       }
       tile[i] = x;
     }
@@ -176,23 +176,22 @@ __global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
     if (m < m1) {
       const unsigned long long P = pos(m);
       const unsigned j = (unsigned)(P % p.nfilts);
-      const float a = (float)((p.a0 + m * p.a) & kMask) * (1.0f / (float)(1u << kFracBits));
       const float2 *__restrict__ x = tile + ((long long)(P / p.nfilts) - (long long)(K - 1) - s_lo);
       const float2 *__restrict__ f = bank + j * KP;
-      float re0 = 0, im0 = 0, re1 = 0, im1 = 0;                  // two chains for latency
-      unsigned k = 0;
-      for (; k + 2 <= K; k += 2) {
-        const float2 t0 = f[k], t1 = f[k + 1], v0 = x[k], v1 = x[k + 1];
-        const float h0 = __builtin_fmaf(a, t0.y, t0.x), h1 = __builtin_fmaf(a, t1.y, t1.x);
-        re0 = __builtin_fmaf(h0, v0.x, re0); im0 = __builtin_fmaf(h0, v0.y, im0);
-        re1 = __builtin_fmaf(h1, v1.x, re1); im1 = __builtin_fmaf(h1, v1.y, im1);
+      // volk_32fc_32f_dot_prod_32fc (generic) twice: sequential float accumulation, product rounded before the add
+      float re0 = 0, im0 = 0, re1 = 0, im1 = 0;
+#pragma unroll 4
+      for (unsigned k = 0; k < K; k++) {
+        const float2 tp = f[k], v = x[k];
+        re0 += v.x * tp.x; im0 += v.y * tp.x;
+        if (INTERP) { re1 += v.x * tp.y; im1 += v.y * tp.y; }
       }
-      if (k < K) {
-        const float2 t0 = f[k], v0 = x[k];
-        const float h0 = __builtin_fmaf(a, t0.y, t0.x);
-        re0 = __builtin_fmaf(h0, v0.x, re0); im0 = __builtin_fmaf(h0, v0.y, im0);
+      float2 o = make_float2(re0, im0);
+      if (INTERP) {                                              // o0 + o1*d_acc
+        const float a = (float)((p.a0 + m * p.a) & kMask) * (1.0f / (float)(1u << kFracBits));
+        o.x = re0 + re1 * a; o.y = im0 + im1 * a;
       }
-      p.out[m] = make_float2(re0 + re1, im0 + im1);
+      p.out[m] = o;
     }
   }
 }
@@ -643,7 +642,8 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
                          (const void *)&lora_chan::chan_general_kernel<false, 2>, (const void *)&lora_chan::chan_general_kernel<true, 2>};
     for (const void *f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGeneralTileSamples * 8) != hipSuccess) return fail(LORA_HIP_EHIP);
-    const void *arb[] = {(const void *)&lora_chan::chan_arb_kernel<false>, (const void *)&lora_chan::chan_arb_kernel<true>};
+    const void *arb[] = {(const void *)&lora_chan::chan_arb_kernel<false, false>, (const void *)&lora_chan::chan_arb_kernel<true, false>,
+                         (const void *)&lora_chan::chan_arb_kernel<false, true>, (const void *)&lora_chan::chan_arb_kernel<true, true>};
     for (const void *f : arb)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kArbLdsBytes) != hipSuccess) return fail(LORA_HIP_EHIP);
   }
@@ -657,7 +657,7 @@ int lora_hip_chan_force_general(lora_hip_chan_t *h, int on) {
   h->force_general = on != 0;
   const DecimVariant *v = pick_decim(h);
   if (v) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch);
-  else if (h->a != 0 && arb_fits(h)) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_arb_kernel");
+  else if (arb_fits(h)) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_arb_kernel");
   else snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel");
   return LORA_HIP_OK;
 }
@@ -768,8 +768,8 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
         p.rot_lane = h->d_rot_lane;
       }
       hipLaunchKernelGGL(v->fn[rot ? 1 : 0], dim3(blocks), dim3(lora_chan::kBlock), 0, h->stream, p);
-    } else if (mode == 1 && arb_fits(h)) {
-      // fractional rate, banks in LDS: outputs per tile = as many as keep the tile's input span in what is left
+    } else if (mode != 2 && arb_fits(h)) {
+      // banks in LDS: outputs per tile = as many as keep the tile's input span in what is left
       const size_t tile_samples = (kArbLdsBytes - arb_bank_bytes(h)) / 8;
       unsigned to = lora_chan::kBlock;
       auto span_of = [&](unsigned t) { return ((unsigned long long)(t - 1) * (h->dec_rate + 1)) / h->nfilts + 2 + h->K; };
@@ -779,8 +779,10 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
       const unsigned long long tiles = (cnt + to - 1) / to;
       unsigned blocks = (unsigned)h->num_cu * 2;
       if (tiles < blocks) blocks = (unsigned)tiles;
-      hipLaunchKernelGGL(rot ? &lora_chan::chan_arb_kernel<true> : &lora_chan::chan_arb_kernel<false>, dim3(blocks),
-                         dim3(lora_chan::kBlock), kArbLdsBytes, h->stream, p);
+      chan_fn fn;
+      if (mode == 1) fn = rot ? &lora_chan::chan_arb_kernel<true, true> : &lora_chan::chan_arb_kernel<false, true>;
+      else fn = rot ? &lora_chan::chan_arb_kernel<true, false> : &lora_chan::chan_arb_kernel<false, false>;
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(lora_chan::kBlock), kArbLdsBytes, h->stream, p);
     } else {
       // outputs per tile: as many as keep the tile's input span inside the LDS tile
       unsigned to = lora_chan::kBlock;
