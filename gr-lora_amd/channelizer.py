@@ -71,6 +71,23 @@ class channelizer:
     def reset(self):
         self._check(lib().lora_hip_chan_reset(self._h))
 
+    def seek(self, n_consumed, history=None):
+        """lora_hip_chan_seek: continue as if n_consumed samples of the stream had been processed; `history` = the
+        taps_per_filter - 1 samples before that position (numpy or torch cuda tensor; None = zeros)."""
+        ptr, flags = None, 0
+        if history is not None:
+            k1 = self.taps_per_filter - 1
+            if capi._is_torch(history):
+                assert history.is_cuda and history.is_contiguous() and history.numel() == k1
+                import torch
+                torch.cuda.current_stream(history.device).synchronize()
+                ptr, flags = history.data_ptr(), capi.IQ_ON_DEVICE
+            else:
+                history = np.ascontiguousarray(history, np.complex64)
+                assert len(history) == k1
+                ptr = history.ctypes.data
+        self._check(lib().lora_hip_chan_seek(self._h, int(n_consumed), ptr, flags))
+
     def output_count(self, n_in):
         return lib().lora_hip_chan_output_count(self._h, int(n_in))
 

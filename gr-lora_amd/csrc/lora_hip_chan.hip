@@ -697,6 +697,37 @@ int lora_hip_chan_reset(lora_hip_chan_t *h) {
   return LORA_HIP_OK;
 }
 
+int lora_hip_chan_seek(lora_hip_chan_t *h, uint64_t n_consumed, const lora_c32 *history, unsigned flags) {
+  if (!h || (flags & ~(unsigned)LORA_HIP_IQ_ON_DEVICE) || n_consumed > ((uint64_t)1 << 56)) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  CHAN_TRY(h, guard.err);
+  // the state after n_consumed samples of a fresh stream
+  h->j = h->j_init; h->acc = 0; h->skip = 0;
+  if (n_consumed) {
+    if (h->frac) {
+      unsigned long long p0 = 0, a0 = 0;
+      const size_t cnt = frac_count(h, (size_t)n_consumed, &p0, &a0);
+      const u128 pn = frac_pos(h, p0, a0, cnt) - (u128)n_consumed * h->nfilts;
+      h->j = (unsigned)(pn % h->nfilts); h->skip = (size_t)(pn / h->nfilts);
+      h->acc = ldexpf((float)((a0 + (unsigned long long)cnt * h->a) & kFracMask), -kFracBits);
+    } else {
+      Recur st{h->j, h->acc, h->skip};
+      run_recurrence(h, st, (size_t)n_consumed, nullptr, nullptr);
+      h->j = st.j; h->acc = st.acc; h->skip = st.skip;
+    }
+  }
+  h->n_abs = n_consumed;
+  const size_t k1 = h->K > 1 ? h->K - 1 : 0;
+  float2 *carry = h->d_carry[h->cur_carry];
+  if (k1) {
+    if (!history) CHAN_TRY(h, hipMemsetAsync(carry, 0, k1 * sizeof(float2), h->stream));
+    else CHAN_TRY(h, hipMemcpyAsync(carry, history, k1 * sizeof(float2),
+                                    (flags & LORA_HIP_IQ_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    CHAN_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return LORA_HIP_OK;
+}
+
 size_t lora_hip_chan_output_count(lora_hip_chan_t *h, size_t n_in) {
   if (!h) return 0;
   if (h->frac) return frac_count(h, n_in, nullptr, nullptr);

@@ -195,3 +195,19 @@ def demod_long_capture(samples, make_block, sf, sweep, dst=0):
     pdus = blk.work(samples)
     blk._shard_stats = dict(getattr(blk, "stats", {}))
     return pdus
+
+
+# ---- channeliser: time segments of one wideband capture (include/lora_hip_chan.h, lora_hip_chan_seek) ----------
+def channelize_segment(samples, chan, rank, world):
+    """This rank's share of channelising one long capture: the contiguous segment my_range(len(samples), rank, world)
+    of the input, entered with lora_hip_chan_seek (closed-form state, taps_per_filter - 1 samples of history read
+    from the capture).  The per-rank outputs, concatenated in rank order, are the sequential stream's output;
+    no samples are exchanged between ranks."""
+    lo, hi = my_range(len(samples), rank, world)
+    k1 = chan.taps_per_filter - 1
+    hist = np.zeros(k1, np.complex64)
+    take = min(k1, lo)
+    if take:
+        hist[k1 - take:] = samples[lo - take:lo]
+    chan.seek(lo, hist)
+    return chan.work(np.ascontiguousarray(samples[lo:hi]))

@@ -43,6 +43,15 @@ LORA_HIP_API const char *lora_hip_chan_last_hip_error(const lora_hip_chan_t *h);
 /* back to the state after create(): history zeroed, first arm, phase 0 */
 LORA_HIP_API int lora_hip_chan_reset(lora_hip_chan_t *h);
 
+/* Put the stream state where it is after n_consumed input samples of a stream that started at reset(): filter
+ * arm, interpolation weight, input overshoot and rotation phase come from the closed form of the reference's
+ * recurrence (no pass over the samples); `history` holds the taps_per_filter - 1 samples before that position
+ * (host pointer, or device pointer with LORA_HIP_IQ_ON_DEVICE; NULL = zeros).  work() on the samples from
+ * n_consumed on then produces exactly what the sequential stream produces there, so one long wideband capture
+ * can be cut into time segments, one per GPU, with taps_per_filter - 1 samples of overlap and no exchange
+ * between the GPUs (no counterpart in the reference, which is one sequential thread per block). */
+LORA_HIP_API int lora_hip_chan_seek(lora_hip_chan_t *h, uint64_t n_consumed, const lora_c32 *history, unsigned flags);
+
 /* Number of output samples the next work() call with n_in inputs will produce (the index recurrence of
  * kernel::pfb_arb_resampler_ccf::filter is data-independent).  Does not change the state. */
 LORA_HIP_API size_t lora_hip_chan_output_count(lora_hip_chan_t *h, size_t n_in);

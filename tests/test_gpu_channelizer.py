@@ -323,3 +323,30 @@ def test_full_size_properties(g):
     y_sum = ch.work(tone(fc + delta) + tone(fc + 0.25, 0.5))
     assert (y_sum - (y_in + 0.5 * y_out)).abs().max().item() < 5e-6
     ch.close()
+
+
+@pytest.mark.parametrize("rate,offset,world", [(0.25, 0.0, 4), (0.3, 0.0, 3), (0.125, 0.0, 8), (1.5, 0.0, 2), (0.25, -0.25, 4),
+                                               (0.3, 0.2, 5)])
+def test_time_segments_of_one_capture(rate, offset, world, g):
+    """lora_hip_chan_seek: the capture cut into `world` time segments, each entered with the closed-form stream
+    state and K-1 samples of history (what one rank per GPU would do, shard.channelize_segment), concatenates to
+    the sequential stream: bit for bit with the rotation off, within 2e-6 with it (tile phases start elsewhere)."""
+    from importlib import import_module
+    shard = import_module("gr-lora_amd.shard")
+    taps = None if rate < 1 else (np.hamming(32 * 12 + 5) * np.sinc(np.linspace(-6, 6, 32 * 12 + 5))).astype(np.float32)
+    x = noise(400_003, 17)
+    ch = g.channelizer(2 * math.pi * offset, rate, taps)
+    whole = ch.work(x).copy()
+    parts = [shard.channelize_segment(x, ch, r, world).copy() for r in range(world)]
+    got = np.concatenate(parts)
+    assert len(got) == len(whole) and all(len(p) > 0 for p in parts)
+    if offset == 0.0:
+        assert np.array_equal(got, whole)
+    else:
+        assert rel_max(got, whole) <= 2e-6
+    # a segment can also be entered out of order, and seek(0) is reset()
+    ch.reset()
+    first = ch.work(x[:50_000]).copy()
+    ch.seek(0)
+    assert np.array_equal(ch.work(x[:50_000]), first)
+    ch.close()
