@@ -350,3 +350,28 @@ def test_time_segments_of_one_capture(rate, offset, world, g):
     ch.seek(0)
     assert np.array_equal(ch.work(x[:50_000]), first)
     ch.close()
+
+
+def test_committed_golden_vectors(g):
+    """tests/golden/chan_golden.npz: fixed expected outputs (recorded from the oracle, generator committed): rotation
+    off -> bit for bit on the kernels that keep the reference's order, 4e-6 on the decimation kernel; rotation on ->
+    5e-5 (2048 samples: the reference chain's drift is below 1e-6 here)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chan_golden.npz"), allow_pickle=False)
+    x = gold["x"]
+    n_cases = sum(1 for k in gold.files if k.endswith("_rate"))
+    names = set()
+    for k in range(n_cases):
+        rate, off, taps, want = float(gold[f"c{k}_rate"]), float(gold[f"c{k}_offset"]), gold[f"c{k}_taps"], gold[f"c{k}_out"]
+        ch = g.channelizer(2 * math.pi * off, rate, taps)
+        got = ch.work(x[:int(gold[f"c{k}_n"])])
+        names.add(ch.kernel_name.split("<")[0])
+        assert len(got) == len(want), k
+        if off == 0.0 and not ch.kernel_name.startswith("chan_decim"):
+            assert np.array_equal(got, want), (k, ch.kernel_name)
+        elif off == 0.0:
+            assert rel_max(got, want) <= 4e-6, k
+        else:
+            assert rel_max(got, want) <= 5e-5, k
+        ch.close()
+    assert names == {"chan_decim_kernel", "chan_arb_kernel", "chan_general_kernel"}
