@@ -401,7 +401,7 @@ struct lora_hip_chan {
   float acc = 0;
   size_t skip = 0;                       // inputs of the next call already stepped over
   unsigned long long n_abs = 0;          // samples consumed so far (rotation phase)
-  // d_flt_rate as an integer count of 2^-24 when the float recurrence is exact (see frac_exact below)
+  // d_flt_rate as an integer count of 2^-24 when the float recurrence is exact (see frac_pos below)
   bool frac = false;
   unsigned long long a = 0;
   bool force_general = false;
