@@ -84,6 +84,7 @@ struct lora_demod_core {
   std::vector<Run> pre_runs;     // handed in through lora_demod_core_preload
   std::vector<Run> sfd_runs;     // one per detect-lattice phase that has needed a sweep, bounded (16 phases)
   unsigned sfd_misses[OVERLAP_FACTOR] = {0};
+  uint64_t sfd_last_miss[OVERLAP_FACTOR] = {0};
   bool staged = false;
   // instrumentation
   lora_core_trace *trace = nullptr; size_t max_trace = 0;
@@ -204,10 +205,13 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
 // The window at absolute position p of a sync attempt whose calls sit on the detect lattice of phase
 // phi = call_pos mod N uses the chirp offset (p - phi) mod N (:297, d_offset = ol*N/16 and read indices move by N
 // between the calls of one attempt): its result depends on (p, phi) only, not on which call or attempt asks.  One
-// stride-N/16 sweep therefore serves every later attempt on the same lattice phase.  The first sweep of a phase
-// covers one attempt (at most 10 calls x 16 windows, :283-292); when the same phase needs a second one, packets
-// keep arriving on it, and the sweep runs far ahead: a window costs the GPU nanoseconds, a launch and its
-// synchronisation tens of microseconds (dense traffic: one launch per packet before, 386 -> 32 launches).
+// stride-N/16 sweep therefore serves every later attempt on the same lattice phase.  How far a sweep runs ahead
+// follows the traffic: a launch and its synchronisation cost about 30 us, a window the GPU, the copy back and the
+// host about N*F/1200 ns (more at high SF), so sweeping the gap to the next attempt on this phase pays when the
+// gap -- taken from the last two misses of the phase -- is shorter than the windows one launch is worth.  Dense
+// traffic (a packet every ~85 symbol times): 458 -> 92 launches per 386 packets; sparse traffic (the 1-hour
+// capture of BASELINE configs[4], a packet per second): gaps are too long, every attempt keeps its own sweep of at
+// most 10 calls x 16 windows (:283-292), as before.
 int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx) {
   const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
   size_t k;
@@ -226,9 +230,17 @@ int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short 
   const size_t avail = (size_t)((end - first - n) / step + 1);
   const unsigned phase = (unsigned)((call_pos % n) / step);
   const size_t one_attempt = (size_t)OVERLAP_FACTOR * 10 + OVERLAP_FACTOR;
-  // far ahead = about 0.3 ms of GPU work whatever the spreading factor (a window costs ~N/400 ns)
-  const size_t far_ahead = ((size_t)1 << 27) >> c->d_sf < ((size_t)1 << 17) ? ((size_t)1 << 27) >> c->d_sf : ((size_t)1 << 17);
-  const size_t want = (++c->sfd_misses[phase] >= 2) ? far_ahead : one_attempt;
+  size_t want = one_attempt;
+  if (c->sfd_misses[phase]++ > 0) {
+    const double window_ns = (double)n * c->d_fft_size_factor / 1200.0 * (1.0 + 0.17 * ((double)c->d_sf - 8.0));
+    const double worth = 30000.0 / (window_ns > 0.1 ? window_ns : 0.1);          // windows one launch is worth (15 us measured worse)
+    const uint64_t gap = (first - c->sfd_last_miss[phase]) / step;               // windows since this phase's last miss
+    if ((double)gap <= worth) {
+      const uint64_t ahead = 8 * gap, cap = (uint64_t)1 << 17;
+      want = (size_t)(ahead < one_attempt ? one_attempt : (ahead < cap ? ahead : cap));
+    }
+  }
+  c->sfd_last_miss[phase] = first;
   c->sfd_runs.emplace_back();
   int rc = launch_run(c, c->sfd_runs.back(), first, step, avail < want ? avail : want, off, step, LORA_WIN_SFD);
   if (rc) { c->sfd_runs.pop_back(); return rc; }
@@ -376,6 +388,7 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->base = 0; c->pos = 0;
   c->up_runs.clear(); c->pre_runs.clear(); c->sfd_runs.clear();
   for (unsigned &m : c->sfd_misses) m = 0;
+  for (uint64_t &m : c->sfd_last_miss) m = 0;
   c->staged = false;
   c->n_calls = 0; c->n_windows = 0; c->n_launches = 0;
   c->err.clear();
