@@ -205,25 +205,30 @@ __global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
 // and row length = 16/D (mod 16), which keeps both the de-interleaving writes and the window reads free of
 // bank conflicts.  The next tile's samples are loaded into registers before the multiply-adds of the current
 // one start, so that HBM latency hides behind them.
+constexpr int decim_lanes(int d) { return d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : 16; }   // lanes per group: next power of two
 template <int D, int NCH>
 struct DecimGeom {
-  static constexpr int Q8 = NCH * 8, R = 8, G = kBlock / D, TOB = R * G;
+  // LG lanes form a group; lane ph < D owns component ph, the others (D not a power of two) hold zero taps
+  static constexpr int LG = decim_lanes(D);
+  static constexpr int Q8 = NCH * 8, R = 8, G = kBlock / LG, TOB = R * G;
   static constexpr int W = TOB + Q8 - 1;                               // window entries per component
   static constexpr int RL0 = W + (W >> 3) + 1;
-  static constexpr int RL = RL0 + ((16 / D - RL0 % 16) + 16) % 16;     // = 16/D (mod 16)
+  static constexpr int RL = RL0 + ((16 / LG - RL0 % 16) + 16) % 16;    // = 16/LG (mod 16)
   static constexpr int NI = (D * W + kBlock - 1) / kBlock;             // loads per thread per tile
+  static_assert(D >= 2 && D <= 16, "whole-number decimation by 2..16");
   static_assert(NI <= kMaxSteps, "rotation step table too small");
-  static_assert(RL % 16 == (16 / D) % 16, "row length residue");
-  static_assert((kBlock / D) % 8 == 0 && R % 8 == 0, "pad split: thread part and constant part never carry");
+  static_assert(RL % 16 == (16 / LG) % 16, "row length residue");
+  static_assert((kBlock / LG) % 8 == 0 && R % 8 == 0, "pad split: thread part and constant part never carry");
 };
 
 template <int D, int NCH, bool ROT>
 __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) {
   using Gm = DecimGeom<D, NCH>;
-  constexpr int Q8 = Gm::Q8, R = Gm::R, TOB = Gm::TOB, W = Gm::W, RL = Gm::RL, NI = Gm::NI;
+  constexpr int Q8 = Gm::Q8, R = Gm::R, TOB = Gm::TOB, W = Gm::W, RL = Gm::RL, NI = Gm::NI, LG = Gm::LG;
   __shared__ float2 L[D * RL];
   const int tid = threadIdx.x;
-  const int ph = tid % D, grp = tid / D;
+  const int ph = tid % LG, grp = tid / LG;
+  const bool owner = ph < D;                                           // lanes beyond D (D not a power of two) carry zero taps
   const unsigned K = p.K;
   // this lane's taps: g[D*q + ph] = reversed arm [K-1 - (D*q + ph)], zero beyond the arm
   float gp[Q8];
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
 #pragma unroll
     for (int q = 0; q < Q8; q++) {
       const unsigned u = (unsigned)(D * q + ph);
-      gp[q] = u < K ? arm[K - 1 - u] : 0.0f;
+      gp[q] = (owner && u < K) ? arm[K - 1 - u] : 0.0f;
     }
   }
   // rotation: phase of the tile's first sample in double, advanced by one grid stride per iteration
@@ -273,14 +278,28 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
     {
       float2 pt = make_float2(1.0f, 0.0f);
       if (ROT) pt = cmul_f(make_float2((float)br, (float)bi), lane_rot);
-      float2 *row = L + (D - 1 - ph) * RL + grp + (grp >> 3);
-      constexpr int GI = kBlock / D;                                   // e / D = grp + GI*i; GI*i is a multiple of 8
+      if constexpr (LG == D) {
+        float2 *row = L + (D - 1 - ph) * RL + grp + (grp >> 3);
+        constexpr int GI = kBlock / D;                                 // e / D = grp + GI*i; GI*i is a multiple of 8
 #pragma unroll
-      for (int i = 0; i < NI; i++) {
-        if (i < NI - 1 || tid + kBlock * i < D * W) {
-          float2 x = xs[i];
-          if (ROT) x = cmul_f(x, cmul_f(pt, p.rot_step[i]));             // FMA form: the phase is exact here, the product order is not the contract
-          row[GI * i + ((GI * i) >> 3)] = x;
+        for (int i = 0; i < NI; i++) {
+          if (i < NI - 1 || tid + kBlock * i < D * W) {
+            float2 x = xs[i];
+            if (ROT) x = cmul_f(x, cmul_f(pt, p.rot_step[i]));           // FMA form: the phase is exact here, the product order is not the contract
+            row[GI * i + ((GI * i) >> 3)] = x;
+          }
+        }
+      } else {
+        // D not a power of two: element e = tid + 256*i goes to component D-1 - e%D, entry e/D (division by a constant)
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          const int e = tid + kBlock * i;
+          if (i < NI - 1 || e < D * W) {
+            float2 x = xs[i];
+            if (ROT) x = cmul_f(x, cmul_f(pt, p.rot_step[i]));
+            const int a = e / D, b = e - a * D;
+            L[(D - 1 - b) * RL + a + (a >> 3)] = x;
+          }
         }
       }
       if (ROT) {                        // advance the tile phase by one grid stride (double complex product)
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
     {
       // window values come from LDS in batches of 8, one batch ahead of the multiply-adds that use it; the
       // scheduling barriers keep the compiler from hoisting every read to the top
-      const float2 *rowp = L + ph * RL + (R + R / 8) * grp;             // pad(R*grp + c) = 9*grp + c + (c >> 3)
+      const float2 *rowp = L + (owner ? ph : 0) * RL + (R + R / 8) * grp;   // pad(R*grp + c) = 9*grp + c + (c >> 3)
       constexpr int NC = R + Q8 - 1, CB = 8, NB = (NC + CB - 1) / CB;
       float2 xb[2][CB];
 #pragma unroll
@@ -338,15 +357,15 @@ __global__ __launch_bounds__(kBlock, 4) void chan_decim_kernel(const CParams p) 
         acc[r].y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[r].y), ctrl, 0xF, 0xF, false)); \
       }                                                                                                      \
     }
-    if (D >= 2) CHAN_DPP_ADD(0xB1)      // quad_perm [1,0,3,2]
-    if (D >= 4) CHAN_DPP_ADD(0x4E)      // quad_perm [2,3,0,1]
-    if (D >= 8) CHAN_DPP_ADD(0x141)     // row_half_mirror
-    if (D >= 16) CHAN_DPP_ADD(0x140)    // row_mirror
+    if (LG >= 2) CHAN_DPP_ADD(0xB1)     // quad_perm [1,0,3,2]
+    if (LG >= 4) CHAN_DPP_ADD(0x4E)     // quad_perm [2,3,0,1]
+    if (LG >= 8) CHAN_DPP_ADD(0x141)    // row_half_mirror
+    if (LG >= 16) CHAN_DPP_ADD(0x140)   // row_mirror
 #undef CHAN_DPP_ADD
     {
       // every lane of a group holds all R sums now; lane ph keeps the PER consecutive outputs ph*PER.. (a select
       // chain over compile-time register indices) so that a wave stores one contiguous run, 16 bytes per lane
-      constexpr int PER = (D <= R) ? R / D : 1, ACT = (D <= R) ? D : R;   // outputs per lane, storing lanes per group
+      constexpr int PER = (LG <= R) ? R / LG : 1, ACT = (LG <= R) ? LG : R;   // outputs per lane, storing lanes per group
       float2 mine[PER];
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -459,6 +478,8 @@ struct DecimVariant { int D, nch; chan_fn fn[2]; int tob, ni; };
 const DecimVariant kDecim[] = {
     CHAN_DV(2, 2), CHAN_DV(2, 3), CHAN_DV(2, 4), CHAN_DV(4, 2), CHAN_DV(4, 3), CHAN_DV(4, 4),
     CHAN_DV(8, 2), CHAN_DV(8, 3), CHAN_DV(8, 4), CHAN_DV(16, 2), CHAN_DV(16, 3), CHAN_DV(16, 4),
+    // decimations that are not a power of two (3 taps chunks = what the 100 dB design needs; others run chan_arb_kernel)
+    CHAN_DV(3, 3), CHAN_DV(5, 3), CHAN_DV(6, 3), CHAN_DV(7, 3), CHAN_DV(10, 3), CHAN_DV(12, 3),
 };
 const DecimVariant *pick_decim(const lora_hip_chan *h) {
   if (h->force_general || h->flt_rate != 0.0f || h->dec_rate == 0 || h->dec_rate % h->nfilts) return nullptr;

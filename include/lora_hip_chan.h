@@ -76,7 +76,7 @@ LORA_HIP_API float lora_hip_chan_flt_rate(const lora_hip_chan_t *h);        /* d
  * ~1e-7 rad, which is 6 rad over 64 M samples */
 LORA_HIP_API double lora_hip_chan_phase_inc_effective(const lora_hip_chan_t *h);
 /* name of the kernel work() dispatches to: "chan_decim_kernel<D,..>" for whole-number decimation (d_flt_rate
- * 0, d_dec_rate = D * nfilts, D in 2, 4, 8, 16), "chan_arb_kernel" for fractional rates whose filter banks fit LDS,
+ * 0, d_dec_rate = D * nfilts, D in 2..8, 10, 12, 16), "chan_arb_kernel" for other rates whose filter banks fit LDS,
  * "chan_general_kernel" otherwise */
 LORA_HIP_API const char *lora_hip_chan_kernel_name(const lora_hip_chan_t *h);
 /* developer knob: 1 = always run the general kernel (the one that follows the reference's summation order) */

@@ -90,7 +90,8 @@ def test_general_kernel_is_bit_exact(rate, taps, g):
     ch.close()
 
 
-@pytest.mark.parametrize("d,atten", [(2, 100), (4, 100), (8, 100), (16, 100), (4, 60), (8, 130), (4, 170)])
+@pytest.mark.parametrize("d,atten", [(2, 100), (4, 100), (8, 100), (16, 100), (4, 60), (8, 130), (4, 170),
+                                     (3, 100), (5, 100), (6, 100), (7, 100), (10, 100), (12, 100), (6, 60)])
 def test_decim_kernel_within_tolerance(d, atten, g):
     rate = 1.0 / d
     x = noise(300_000, 11 + d)
@@ -99,7 +100,9 @@ def test_decim_kernel_within_tolerance(d, atten, g):
     want_f = ref.work(x)
     ch = g.channelizer(0.0, rate, atten=atten)
     q8 = -(-(-(-ch.taps_per_filter // d)) // 8)
-    assert ch.kernel_name == (f"chan_decim_kernel<{d},{max(q8, 2)}>" if q8 <= 4 else "chan_arb_kernel")   # > 32 taps per component
+    whole = ch.flt_rate == 0.0 and ch.dec_rate == 32 * d          # 1/7 as a float makes 32/rate = 223.99998: fractional
+    fast = whole and (q8 <= 4 if d in (2, 4, 8, 16) else q8 == 3)  # other decimations: the 100 dB design's tap count only
+    assert ch.kernel_name == (f"chan_decim_kernel<{d},{max(q8, 2)}>" if fast else "chan_arb_kernel")
     got = ch.work(x)
     assert len(got) == len(want)
     e_gpu, e_cpu = rel_max(got, want), rel_max(want_f, want)
@@ -109,18 +112,24 @@ def test_decim_kernel_within_tolerance(d, atten, g):
     ch.reset()
     got2 = np.concatenate([ch.work(c) for c in chunks_of(x, [5, 4097, 1, 77_777, 2])])
     assert np.array_equal(got2, got)
+    if fast:                                   # with the rotation on: against the two blocks, drift line taken out
+        rot = g.channelizer(2 * math.pi * 0.123, rate, atten=atten)
+        assert rot.kernel_name == ch.kernel_name
+        want_r = oracle.PfbArbResampler(rate, atten=atten).work(oracle.Rotator(2 * math.pi * 0.123).work(x))
+        assert drift_and_residual(rot.work(x), want_r)[1] <= 5e-5
+        rot.close()
     # and the general kernel on the same stream agrees with the float oracle exactly
     ch.reset(); ch.force_general(True)
     assert np.array_equal(ch.work(x), want_f)
     ch.close()
 
 
-@pytest.mark.parametrize("rate,taps", [(0.3, None), (0.7, None), (0.13, None), (0.9999, None), (0.4, None), (1.0 / 3, None),
+@pytest.mark.parametrize("rate,taps", [(0.3, None), (0.7, None), (0.13, None), (0.9999, None), (0.4, None), (2.0 / 3, None), (1.0 / 7, None),
                                        (1.5, "own"), (2.75, "own"), (1.0, "own")])
 def test_lds_bank_kernel_is_bit_exact(rate, taps, g):
     """chan_arb_kernel (filter banks in LDS) keeps the reference's summation order: bit-identical to the oracle's
-    float evaluation, for fractional rates (interpolating between arms) and for whole-number rates that are
-    not a power-of-two decimation."""
+    float evaluation, for fractional rates (interpolating between arms; 1/7 is one as a float: 32/rate = 223.99998)
+    and for rates that step through the arms without interpolating (0.4, 2/3: d_flt_rate 0, d_dec_rate 80, 48)."""
     if taps == "own":
         taps = (np.hamming(32 * 12 + 5) * np.sinc(np.linspace(-6, 6, 32 * 12 + 5))).astype(np.float32)
     x = noise(200_000, 31)
@@ -243,7 +252,7 @@ def test_random_streams_follow_the_oracle(g):
     for case in range(120):
         kind = rng.integers(0, 3)
         if kind == 0:
-            rate = 1.0 / float(rng.choice([2, 4, 8, 16]))
+            rate = 1.0 / float(rng.choice([2, 4, 8, 16, 3, 5, 6, 10, 12]))
             taps = None if rng.random() < 0.5 else oracle.design_taps(rate, atten=float(rng.choice([40, 80, 120])))
         elif kind == 1:
             rate = float(rng.uniform(0.03, 0.99))
