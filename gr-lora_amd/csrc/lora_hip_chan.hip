@@ -8,9 +8,9 @@
 //     run in parallel and whose rounding depends on the VOLK kernel picked at run time;
 //   * whole-number decimation D (d_flt_rate == 0 and d_dec_rate = D*nfilts: 1 MS/s -> 250 kS/s in the
 //     flowgraph) uses one arm for every output, so the filter bank is a plain decimating FIR:
-//     chan_decim_kernel splits it into its D polyphase components, one lane per component, 16 consecutive
-//     outputs per lane in registers, every LDS value used for up to 16 multiply-adds, then a DPP sum over
-//     the D lanes;
+//     chan_decim_kernel splits it into its D polyphase components, one lane per component, 8 consecutive
+//     outputs per lane in registers, every LDS value used for up to 8 multiply-adds, then a DPP sum over
+//     the lanes of a group;
 //   * any other rate runs chan_arb_kernel (filter banks in LDS) or chan_general_kernel (banks too big for LDS):
 //     one output per lane, arm and interpolation weight per output from the closed form of the reference's
 //     recurrence, taps applied in the reference's order with separately rounded products, so both are
