@@ -23,7 +23,7 @@ assert WIN_DESC_DTYPE.itemsize == 16
 EXPORTS = (
     "lora_hip_strerror", "lora_hip_last_hip_error", "lora_hip_make_chirp_tables", "lora_hip_make_kaiser",
     "lora_hip_demod_create", "lora_hip_demod_destroy", "lora_hip_demod_set_stream", "lora_hip_demod_batch",
-    "lora_hip_demod_batch_strided", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
+    "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
     "lora_hip_demod_kernel_name", "lora_hip_demod_stage_iq", "lora_hip_demod_stage_iq2",
     "lora_hip_demod_stage_iq2_dev", "lora_hip_demod_fetch", "lora_demod_core_work_device", "lora_demod_core_set_stream",
     # include/lora_demod_core.h
@@ -78,6 +78,8 @@ def lib():
     L.lora_hip_demod_batch.argtypes = [vp, vp, sz, vp, sz, vp, vp, u]; L.lora_hip_demod_batch.restype = i
     L.lora_hip_demod_batch_strided.argtypes = [vp, vp, sz, u64, u64, sz, u, u, u, vp, vp, u]
     L.lora_hip_demod_batch_strided.restype = i
+    L.lora_hip_demod_batch_strided_noalloc.argtypes = [vp, vp, sz, u64, u64, sz, u, u, u, vp, vp]
+    L.lora_hip_demod_batch_strided_noalloc.restype = i
     L.lora_hip_demod_sf.argtypes = [vp]; L.lora_hip_demod_sf.restype = u
     L.lora_hip_demod_fft_factor.argtypes = [vp]; L.lora_hip_demod_fft_factor.restype = u
     L.lora_hip_demod_kernel_name.argtypes = [vp]; L.lora_hip_demod_kernel_name.restype = C.c_char_p
@@ -227,6 +229,18 @@ class HipDemod:
         self._check(lib().lora_hip_demod_batch_strided(self._h, pi, n_samples, pos0, stride, count, chirp_off,
                                                        chirp_off_step, kind, po, pv, flags))
         return out_idx, out_val
+
+    def batch_strided_noalloc(self, iq, pos0, stride, count, out_idx, out_val, chirp_off=0, chirp_off_step=0,
+                              kind=WIN_UP):
+        """lora_hip_demod_batch_strided_noalloc: device tensors only, enqueues on the handle's stream and
+        returns; the caller synchronises."""
+        pi, di = _ptr(iq); po, do = _ptr(out_idx); pv, dv = _ptr(out_val)
+        assert di and do and dv, "the no-allocation entry point takes device buffers only"
+        n_samples = iq.numel()
+        if iq.dtype.is_floating_point and not iq.dtype.is_complex:
+            n_samples //= 2
+        self._check(lib().lora_hip_demod_batch_strided_noalloc(self._h, pi, n_samples, pos0, stride, count, chirp_off,
+                                                               chirp_off_step, kind, po, pv))
 
 
 def make_desc(pos, chirp_off, kind):

@@ -7,11 +7,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include <algorithm>
 
 using lora_hip::KParams;
+
+// Scratch of lora_hip_demod_batch_strided_noalloc (callers that cannot allocate): the window-group ticket counters
+// of the persistent kernels, the only device memory they use beyond the caller's inputs and outputs and the
+// handle's tables.  One copy per GPU the library runs on, held until the process ends.  In host code this name is
+// only a stand-in for hipGetSymbolAddress: what reaches a kernel or a memset is the per-device address kept in
+// g_scratch_ptr, taken once per device at lora_hip_demod_create.
+constexpr size_t kScratchWords = lora_hip::kWaveTicketQueues * lora_hip::kTicketStride;   // 32 counters, 128 B apart: 4 KiB
+static __device__ __align__(256) unsigned scratch[kScratchWords];
 
 struct lora_hip_demod {
   int device = 0;
@@ -38,6 +47,10 @@ struct lora_hip_demod {
 };
 
 namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned *g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU, by device index
 
 int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
   if (h) snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e));
@@ -110,7 +123,7 @@ bool pick_variant(unsigned sf, unsigned f, Variant *v) {
   }
 }
 
-int launch(lora_hip_demod *h, KParams &p) {
+int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   Variant v;
   if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
   if (p.n_win == 0) return LORA_HIP_OK;
@@ -125,9 +138,10 @@ int launch(lora_hip_demod *h, KParams &p) {
   p.dbg = h->d_dbg;
 #endif
   {
-    hipError_t em = hipMemsetAsync(h->d_ticket, 0, lora_hip::kWaveTicketQueues * lora_hip::kTicketStride * sizeof(unsigned), h->stream);
+    // the counters must start at zero: the array keeps the previous launch's values
+    hipError_t em = hipMemsetAsync(ticket, 0, kScratchWords * sizeof(unsigned), h->stream);
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
-    p.ticket = h->d_ticket;
+    p.ticket = ticket;
   }
   p.twist = h->d_twist; p.fr = h->fft_factor;
   // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
@@ -291,7 +305,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_down, 2 * n * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_win, n * sizeof(float)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
-  if (hipMalloc((void **)&h->d_ticket, lora_hip::kWaveTicketQueues * lora_hip::kTicketStride * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMalloc((void **)&h->d_ticket, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
@@ -309,6 +323,16 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LORA_HIP_EHIP);
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // the no-allocation entry point's scratch: its address on this device, once per device, with the device current
+  if (device < kMaxDevices) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+      unsigned *sp = nullptr;
+      hipError_t e = hipGetSymbolAddress((void **)&sp, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !sp) { hip_fail(h, e, "hipGetSymbolAddress(scratch)"); return fail(LORA_HIP_EHIP); }
+      g_scratch_ptr[device] = sp;
+    }
   }
   // kernels with more dynamic LDS than the runtime's default limit need the opt-in
   if (v.lds > 48 * 1024) {
@@ -442,7 +466,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
-  if ((rc = launch(h, p)) != LORA_HIP_OK) return rc;
+  if ((rc = launch(h, p, h->d_ticket)) != LORA_HIP_OK) return rc;
   if (!out_dev) {
     const size_t idx_off = n_win * 4;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, n_win * 6, hipMemcpyDeviceToHost, h->stream));
@@ -478,6 +502,37 @@ int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c32 *iq, size_t
   memset(&p, 0, sizeof p);
   p.pos0 = pos0; p.stride = stride; p.off0 = chirp_off; p.off_step = chirp_off_step; p.kind = kind;
   return run_batch(h, iq, n_samples, p, nullptr, count, max_idx, max_val, flags);
+}
+
+int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq_dev, size_t n_samples, uint64_t pos0,
+                                         uint64_t stride, size_t count, unsigned chirp_off, unsigned chirp_off_step,
+                                         unsigned kind, uint16_t *max_idx_dev, float *max_val_dev) {
+  if (!h) return LORA_HIP_EINVAL;
+  if (count > LORA_HIP_NOALLOC_MAX_WINDOWS) {
+    snprintf(h->hip_err, sizeof h->hip_err, "lora_hip_demod_batch_strided_noalloc: %zu windows exceed the maximum of %llu per call",
+             count, (unsigned long long)LORA_HIP_NOALLOC_MAX_WINDOWS);
+    return LORA_HIP_EINVAL;
+  }
+  if (kind > LORA_WIN_SFD || chirp_off >= h->n || chirp_off_step >= h->n) return LORA_HIP_EINVAL;
+  if (count == 0) return LORA_HIP_OK;
+  if (!iq_dev || !max_idx_dev || !max_val_dev || n_samples < h->n) return LORA_HIP_EINVAL;
+  if (pos0 > n_samples || n_samples - pos0 < h->n) return LORA_HIP_EINVAL;
+  if (count > 1 && stride != 0 && (count - 1) > (n_samples - pos0 - h->n) / stride) return LORA_HIP_EINVAL;
+  if (h->device >= kMaxDevices || !g_scratch_ptr[h->device]) return LORA_HIP_ENODEVICE;   // set by create() on this device
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  KParams p;
+  memset(&p, 0, sizeof p);
+  p.pos0 = pos0; p.stride = stride; p.off0 = chirp_off; p.off_step = chirp_off_step; p.kind = kind;
+  p.iq = reinterpret_cast<const float2 *>(iq_dev);
+  p.n_samples = n_samples;
+  p.desc = nullptr;
+  p.out_idx = max_idx_dev; p.out_val = max_val_dev;
+  p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
+  for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
+  p.n_win = (unsigned)count;
+  // enqueue only (a memset of the scratch and the kernel, on the handle's stream): no allocation, no synchronisation
+  return launch(h, p, g_scratch_ptr[h->device]);
 }
 
 }  // extern "C"

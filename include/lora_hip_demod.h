@@ -121,6 +121,28 @@ LORA_HIP_API int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c3
                                               unsigned chirp_off_step, unsigned kind,
                                               uint16_t *max_idx, float *max_val, unsigned flags);
 
+/*
+ * lora_hip_demod_batch_strided for callers that cannot allocate.  It has no counterpart in the reference: it is
+ * for code that must not reach hipMalloc or hipFree -- work recorded under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same windows, same kernels and same results, bit for bit, as
+ * lora_hip_demod_batch_strided with LORA_HIP_IQ_ON_DEVICE | LORA_HIP_OUT_ON_DEVICE | LORA_HIP_ASYNC; the only device
+ * memory the kernels use beyond the caller's buffers and the handle's tables, their window-group ticket counters
+ * (4 KiB), lies in a file-scope __device__ array of the library instead of a buffer the handle allocated.
+ *   - iq_dev, max_idx_dev and max_val_dev are device pointers on the handle's GPU; nothing is copied to or from
+ *     the host and nothing is allocated or freed (no hipMalloc/hipFree/hipHostMalloc, no growth of staging buffers).
+ *   - The call only enqueues a 4 KiB memset of the scratch and the kernel on the handle's stream
+ *     (lora_hip_demod_set_stream); the caller synchronises.
+ *   - count above LORA_HIP_NOALLOC_MAX_WINDOWS is refused with LORA_HIP_EINVAL (text in lora_hip_last_hip_error).
+ *   - Every call on one GPU shares that GPU's scratch array, whatever the handle: calls that overlap in time on one
+ *     GPU (different streams or threads) race on the counters.  Calls queued on one stream are safe.
+ */
+#define LORA_HIP_NOALLOC_MAX_WINDOWS ((size_t)1 << 30)
+LORA_HIP_API int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq_dev,
+                                                      size_t n_samples, uint64_t pos0, uint64_t stride,
+                                                      size_t count, unsigned chirp_off,
+                                                      unsigned chirp_off_step, unsigned kind,
+                                                      uint16_t *max_idx_dev, float *max_val_dev);
+
 /* Copy n_samples host samples into the handle's own HBM staging buffer once, so that several
  * batch calls (flag LORA_HIP_IQ_STAGED) can sweep them without another host-to-device copy.
  * This is what replaces the scheduler-owned input buffer of general_work (:155). */
