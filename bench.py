@@ -10,6 +10,15 @@ capture (1 250 000 samples, chirp packets from the mod layout), replicated R tim
 that >= 1 GiB of IQ is resident (a single capture is only 305 windows, far too short to time).
 Each rank owns its own replicas (independent captures shard, no data-path collective).
 Prints ONE JSON line on rank 0.
+
+Launched by torch.distributed.run (WORLD_SIZE set) every process is one rank.  Started plainly with --gpus N > 1
+(WORLD_SIZE unset) this process becomes a parent that never touches the GPU: it starts N fresh rank processes with
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set and relays rank 0's line.
+
+Before the timed region every rank runs a fixed clock-settling pre-roll (--settle-s seconds of back-to-back launches,
+reported as `settle_launches`): the device boosts for the first few launches, throttles, and settles after a few hundred
+(profiles/r01_launch_trace.txt), so a short --warmup alone would time the transient.  Per-step times (HIP events on the
+launch stream) are reported as min/median/max so that a transient inside the timed region would be visible.
 """
 import argparse
 import json
@@ -64,9 +73,17 @@ def cpu_baseline(capture, budget_s=12.0):
             code = _WORKER % (ROOT, SF, BETA, FFT_FACTOR)
             wreps = max(1, reps // 2)
             t0 = time.perf_counter()
-            procs = [subprocess.Popen([sys.executable, "-c", code, path, str(wreps)], stdout=subprocess.PIPE, text=True)
-                     for _ in range(ncores)]
-            done = [p.communicate(timeout=300)[0].split() for p in procs]
+            procs = []
+            try:
+                for _ in range(ncores):
+                    procs.append(subprocess.Popen([sys.executable, "-c", code, path, str(wreps)],
+                                                  stdout=subprocess.PIPE, text=True))
+                done = [p.communicate(timeout=300)[0].split() for p in procs]
+            finally:
+                for p in procs:                 # never leave a worker behind, whatever happened above
+                    if p.poll() is None:
+                        p.kill()
+                    p.wait()
             wall = time.perf_counter() - t0
         if all(p.returncode == 0 for p in procs):
             total = sum(float(d[1]) for d in done) * wreps
@@ -109,36 +126,84 @@ def channeliser_leg(torch, g, dev, stream, total_bytes=1 << 30, reps=20):
     return res
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: this parent (which has not touched the GPU and never does) starts N rank
+    processes of this file and relays their output; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rcs = [p.wait() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)      # clocks and TLBs settle within ~50 launches (+4 % over warmup 5)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-s", type=float, default=0.5, help="seconds of untimed launches before --warmup (clock settling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: rendezvous, barrier and the JSON line only (CPU test of the launch path)")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import gr_lora_amd as g
-    from importlib import import_module
-    synth = import_module("gr-lora_amd.synth")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    from importlib import import_module
+    synth = import_module("gr-lora_amd.synth")
+    cap = synth.capture(SF, CAPTURE_SAMPLES, symbols_per_packet=64, seed=2 + rank)
+
+    # CPU baseline first, while this process has not initialised the GPU (it builds the oracle and starts worker
+    # processes): rank 0 at N = 1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
+        cpu = cpu_baseline(cap)
+
+    import torch
     if world > 1:
         import torch.distributed as dist
         # The data path has no collective (captures are independent): the process group only carries
         # the timing barrier and the max-over-ranks of two floats, so gloo on the host is enough and
         # RCCL/xGMI stay idle by design.
         dist.init_process_group("gloo")
+    if args.dry_run:
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert float(t[0]) == world
+        if rank == 0:
+            print(json.dumps({"metric": "demodulated symbols/sec (Msym/s) at SF12 fft_factor=2", "value": None,
+                              "unit": "Msym/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    import gr_lora_amd as g
     ndev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)   # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
     n = 1 << SF
-    cap = synth.capture(SF, CAPTURE_SAMPLES, symbols_per_packet=64, seed=2 + rank)
     replicas = -(-MIN_RESIDENT_BYTES // (cap.nbytes))
     iq = torch.from_numpy(cap).to(dev).repeat(replicas)           # complex64, resident in HBM
     torch.cuda.synchronize()                                      # built on torch's stream, read on `stream` below
@@ -175,18 +240,28 @@ def main():
     copy_gbs = 2 * raw.numel() * 4 * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
     del dst, raw
 
+    # clock-settling pre-roll: back-to-back launches for --settle-s seconds, whatever --warmup says
+    settle_launches = 0
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < args.settle_s:
+        for _ in range(50):
+            step()
+        stream.synchronize()
+        settle_launches += 50
     for _ in range(args.warmup):
         step()
     fence()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record(stream)                      # HIP events on the launch stream: kernel time only
-    for _ in range(args.steps):
+    evs[0].record(stream)                   # HIP events on the launch stream: kernel time only
+    for i in range(args.steps):
         step()
-    ev1.record(stream)
+        evs[i + 1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    kernel_ms = evs[0].elapsed_time(evs[-1]) / args.steps
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    step_stats = {"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4), "max": round(per_step[-1], 4)}
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
@@ -222,6 +297,7 @@ def main():
         line = {
             "metric": "demodulated symbols/sec (Msym/s) at SF12 fft_factor=2",
             "value": round(value, 3), "unit": "Msym/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_launches": settle_launches, "kernel_ms_per_step": step_stats,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SF12 fft_factor=2 beta=25, 10 s x 125 kS/s synthetic chirp capture "
@@ -240,8 +316,8 @@ def main():
                 line["next_rows"] = {"channeliser": channeliser_leg(torch, g, dev, stream)}
             except Exception as e:              # the headline line must not depend on this leg
                 line["next_rows"] = {"channeliser": {"error": str(e)[:200]}}
-        if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
-            line["cpu_baseline"] = cpu_baseline(cap)
+        if cpu is not None:                              # reported at N=1 only; measured before the GPU was touched
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     h.close()
     if world > 1:
