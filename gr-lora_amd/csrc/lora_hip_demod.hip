@@ -91,21 +91,29 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
 #define LORA_NO_CONST 0   // developer knob: 1 = never use the register-resident-taps variant
 #endif
 typedef void (*kernel_fn)(const KParams);
-struct Variant { kernel_fn fn, fn_const; size_t lds; int wpb, threads, blocks_per_cu; const char *name; };
+// fn: any window list; fn_const: the strided sweep with one chirp offset (taps in registers), which may have its own geometry
+struct Variant {
+  kernel_fn fn, fn_const; size_t lds; int wpb, threads, blocks_per_cu; const char *name;
+  size_t lds_const; int wpb_const, blocks_per_cu_const; const char *name_const;
+};
 
 template <int LOGN, int F>
 Variant make_variant(const char *name) {
-  return Variant{&lora_hip::demod_kernel<LOGN, F, false>, &lora_hip::demod_kernel<LOGN, F, true>,
-                 lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN, F>(), lora_hip::block_threads(LOGN, F),
-                 lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name};
+  Variant v{&lora_hip::demod_kernel<LOGN, F, false>, &lora_hip::demod_kernel<LOGN, F, true>,
+            lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN, F>(), lora_hip::block_threads(LOGN, F),
+            lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name, 0, 0, 0, name};
+  v.lds_const = v.lds; v.wpb_const = v.wpb; v.blocks_per_cu_const = v.blocks_per_cu;
+  return v;
 }
 
 template <int LOGN>
 Variant make_variant_anyf(const char *name) {
   // no register-resident-taps variant: x stays live across the run-time loop and the registers are needed there
-  return Variant{&lora_hip::demod_kernel<LOGN, 1, false, true>, &lora_hip::demod_kernel<LOGN, 1, false, true>,
-                 lora_hip::demod_lds_bytes<LOGN, 1>(), lora_hip::demod_wpb<LOGN, 1>(), lora_hip::block_threads(LOGN, 1),
-                 lora_hip::min_waves(LOGN, 1) * 4 / (lora_hip::block_threads(LOGN, 1) / 64), name};
+  Variant v{&lora_hip::demod_kernel<LOGN, 1, false, true>, &lora_hip::demod_kernel<LOGN, 1, false, true>,
+            lora_hip::demod_lds_bytes<LOGN, 1>(), lora_hip::demod_wpb<LOGN, 1>(), lora_hip::block_threads(LOGN, 1),
+            lora_hip::min_waves(LOGN, 1) * 4 / (lora_hip::block_threads(LOGN, 1) / 64), name, 0, 0, 0, name};
+  v.lds_const = v.lds; v.wpb_const = v.wpb; v.blocks_per_cu_const = v.blocks_per_cu;
+  return v;
 }
 
 #define LORA_VARIANTS_SF(SF) \
@@ -127,10 +135,31 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   Variant v;
   if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
   if (p.n_win == 0) return LORA_HIP_OK;
+  // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
+  const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
+  const int wpb = const_off ? v.wpb_const : v.wpb;
+  const size_t lds = const_off ? v.lds_const : v.lds;
   // persistent workgroups: at most blocks_per_cu per CU; they share the window groups through ticket counters
-  unsigned blocks = (p.n_win + v.wpb - 1) / v.wpb;
-  const unsigned resident = (unsigned)h->num_cu * (h->blocks_per_cu ? h->blocks_per_cu : (unsigned)v.blocks_per_cu);
+  unsigned blocks = (p.n_win + wpb - 1) / wpb;
+  const unsigned resident = (unsigned)h->num_cu * (h->blocks_per_cu ? h->blocks_per_cu : (unsigned)(const_off ? v.blocks_per_cu_const : v.blocks_per_cu));
   if (blocks > resident) blocks = resident;
+#if LORA_CLOCK
+  {
+    static unsigned long long n_launch = 0;
+    if (!h->d_dbg) (void)hipMalloc((void **)&h->d_dbg, 4096 * 2 * sizeof(unsigned long long));
+    p.dbg = h->d_dbg;
+    if ((++n_launch % 400) == 0) {     // report now and then: the previous launch's numbers
+      std::vector<unsigned long long> hd(2 * blocks);
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipMemcpy(hd.data(), h->d_dbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      std::vector<double> mhz;
+      for (unsigned b = 0; b < blocks; b++) if (hd[2 * b + 1]) mhz.push_back(100.0 * (double)hd[2 * b] / (double)hd[2 * b + 1]);
+      std::sort(mhz.begin(), mhz.end());
+      if (!mhz.empty()) fprintf(stderr, "[clock] launch %llu: in-kernel clock median %.0f MHz (min %.0f max %.0f), lifetime median %.1f us\n",
+                                n_launch, mhz[mhz.size() / 2], mhz.front(), mhz.back(), (double)hd[2 * (blocks / 2) + 1] / 100.0);
+    }
+  }
+#endif
 #if LORA_STAMPS
   const size_t ndbg = (size_t)blocks * (v.threads / 64) * 8;
   if (!h->d_dbg) (void)hipMalloc((void **)&h->d_dbg, (size_t)h->num_cu * 8 * 4 * 8 * sizeof(unsigned long long));
@@ -144,9 +173,7 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
     p.ticket = ticket;
   }
   p.twist = h->d_twist; p.fr = h->fft_factor;
-  // one chirp offset for the whole sweep (the steady-state stride-N path): taps stay in registers
-  const bool const_off = (p.desc == nullptr && p.off_step == 0) && !LORA_NO_CONST;
-  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), v.lds, h->stream, p);
+  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), lds, h->stream, p);
 #if LORA_STAMPS
   {
     std::vector<unsigned long long> hd(ndbg);
@@ -252,7 +279,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   h->anyf = (fft_factor != 1 && fft_factor != 2 && fft_factor != 4);
   Variant v;
   pick_variant(sf, fft_factor, &v);
-  h->kernel_name = v.name;
+  h->kernel_name = v.name_const;   // the kernel of the steady-state sweep
   if (const char *e = getenv("LORA_HIP_BLOCKS_PER_CU")) { int b = atoi(e); if (b >= 1 && b <= 8) h->blocks_per_cu = (unsigned)b; }   // tuning knob
 
   const size_t n = h->n, m = h->m;
@@ -335,9 +362,9 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
     }
   }
   // kernels with more dynamic LDS than the runtime's default limit need the opt-in
-  if (v.lds > 48 * 1024) {
+  if (v.lds > 48 * 1024 || v.lds_const > 48 * 1024) {
     if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_const) != hipSuccess)
       return fail(LORA_HIP_EHIP);
   }
   *out = h;

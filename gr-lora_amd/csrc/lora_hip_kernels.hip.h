@@ -21,6 +21,12 @@
 
 namespace lora_hip {
 
+// buffer_load_dwordx2 through the LLVM intrinsic (the clang builtin of this toolchain narrows b64 loads to one dword):
+// descriptor in four SGPRs, per-lane byte offset in one VGPR, a scalar byte offset per load
+typedef int buf_rsrc_t __attribute__((ext_vector_type(4)));
+typedef float buf_v2f_t __attribute__((ext_vector_type(2)));
+__device__ buf_v2f_t buffer_load_v2f32(buf_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+
 struct KParams {
   const float2 *iq;             // capture (device)
   unsigned long long n_samples;
@@ -118,34 +124,87 @@ template <> struct Dft<8> {
   }
 };
 
+// Butterflies with the multiply folded in (every operation an FMA): a0 = p + w*b, a1 = p - w*b in 6 instructions instead of
+// the 8 of a complex multiply followed by an add and a subtract; a1 = 2p - a0 reuses the sum.  The error stays
+// O(eps * max(|p|, |b|)), as for the separate form.
+__device__ __forceinline__ void bfly_tw(const float2 p, const float2 w, const float2 b, float2 &a0, float2 &a1) {
+  a0.x = __builtin_fmaf(-w.y, b.y, __builtin_fmaf(w.x, b.x, p.x));
+  a0.y = __builtin_fmaf(w.y, b.x, __builtin_fmaf(w.x, b.y, p.y));
+  a1.x = __builtin_fmaf(2.0f, p.x, -a0.x);
+  a1.y = __builtin_fmaf(2.0f, p.y, -a0.y);
+}
+// w = (1 - j)/sqrt2 (W8^1): w*b = ((b.x + b.y), (b.y - b.x)) / sqrt2
+__device__ __forceinline__ void bfly_w8_1(const float2 p, const float2 b, float2 &a0, float2 &a1) {
+  const float t1 = b.x + b.y, t2 = b.y - b.x;
+  a0 = make_float2(__builtin_fmaf(LORA_SQRT1_2, t1, p.x), __builtin_fmaf(LORA_SQRT1_2, t2, p.y));
+  a1 = make_float2(__builtin_fmaf(-LORA_SQRT1_2, t1, p.x), __builtin_fmaf(-LORA_SQRT1_2, t2, p.y));
+}
+// w = (-1 - j)/sqrt2 (W8^3): w*b = ((b.y - b.x), -(b.x + b.y)) / sqrt2
+__device__ __forceinline__ void bfly_w8_3(const float2 p, const float2 b, float2 &a0, float2 &a1) {
+  const float t1 = b.y - b.x, t2 = b.x + b.y;
+  a0 = make_float2(__builtin_fmaf(LORA_SQRT1_2, t1, p.x), __builtin_fmaf(-LORA_SQRT1_2, t2, p.y));
+  a1 = make_float2(__builtin_fmaf(-LORA_SQRT1_2, t1, p.x), __builtin_fmaf(LORA_SQRT1_2, t2, p.y));
+}
+__device__ __forceinline__ void dft4_tail(const float2 a0, const float2 a1, const float2 a2, const float2 a3d,
+                                          float2 &y0, float2 &y1, float2 &y2, float2 &y3) {
+  const float2 a3 = mul_mj(a3d);
+  y0 = cadd(a0, a2); y2 = csub(a0, a2); y1 = cadd(a1, a3); y3 = csub(a1, a3);
+}
+
 template <> struct Dft<16> {
-  __device__ static __forceinline__ void run(float2 *x) {
+  // TW: inputs 1..15 are first multiplied by w[1..15] (the pass twiddles); folded into the first butterflies
+  // 150 instructions untwiddled, 194 with the 15 twiddles (164 and 224 with separate multiplies)
+  template <bool TW>
+  __device__ static __forceinline__ void run_impl(float2 *x, const float2 *w) {
     // 4x4: u[c][k1] = DFT4 over m of x[c + 4m]
     float2 u[4][4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      u[c][0] = x[c]; u[c][1] = x[c + 4]; u[c][2] = x[c + 8]; u[c][3] = x[c + 12];
-      dft4(u[c][0], u[c][1], u[c][2], u[c][3]);
+      float2 a0, a1, a2, a3;
+      if constexpr (TW) {
+        const float2 p0 = (c == 0) ? x[0] : cmul(x[c], w[c]);
+        const float2 p1 = cmul(x[c + 4], w[c + 4]);
+        bfly_tw(p0, w[c + 8], x[c + 8], a0, a1);
+        bfly_tw(p1, w[c + 12], x[c + 12], a2, a3);
+      } else {
+        a0 = cadd(x[c], x[c + 8]); a1 = csub(x[c], x[c + 8]);
+        a2 = cadd(x[c + 4], x[c + 12]); a3 = csub(x[c + 4], x[c + 12]);
+      }
+      dft4_tail(a0, a1, a2, a3, u[c][0], u[c][1], u[c][2], u[c][3]);
     }
-    // twiddles W16^(c*k1)
-    const float2 w1 = make_float2(LORA_COS_PI_8, -LORA_SIN_PI_8);
-    const float2 w3 = make_float2(LORA_SIN_PI_8, -LORA_COS_PI_8);
-    u[1][1] = cmul(u[1][1], w1);
-    u[1][2] = make_float2((u[1][2].x + u[1][2].y) * LORA_SQRT1_2, (u[1][2].y - u[1][2].x) * LORA_SQRT1_2);
-    u[1][3] = cmul(u[1][3], w3);
-    u[2][1] = make_float2((u[2][1].x + u[2][1].y) * LORA_SQRT1_2, (u[2][1].y - u[2][1].x) * LORA_SQRT1_2);
-    u[2][2] = mul_mj(u[2][2]);
-    u[2][3] = make_float2((u[2][3].y - u[2][3].x) * LORA_SQRT1_2, -(u[2][3].x + u[2][3].y) * LORA_SQRT1_2);
-    u[3][1] = cmul(u[3][1], w3);
-    u[3][2] = make_float2((u[3][2].y - u[3][2].x) * LORA_SQRT1_2, -(u[3][2].x + u[3][2].y) * LORA_SQRT1_2);
-    u[3][3] = cmul(u[3][3], make_float2(-LORA_COS_PI_8, LORA_SIN_PI_8));   // W16^9
-    // y[k1 + 4 k2] = DFT4 over c of u[c][k1]
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) {
-      dft4(u[0][k1], u[1][k1], u[2][k1], u[3][k1]);
-      x[k1] = u[0][k1]; x[k1 + 4] = u[1][k1]; x[k1 + 8] = u[2][k1]; x[k1 + 12] = u[3][k1];
+    // y[k1 + 4 k2] = DFT4 over c of u[c][k1] * W16^(c*k1)
+    const float2 w1 = make_float2(LORA_COS_PI_8, -LORA_SIN_PI_8);     // W16^1
+    const float2 w3 = make_float2(LORA_SIN_PI_8, -LORA_COS_PI_8);     // W16^3
+    const float2 w9 = make_float2(-LORA_COS_PI_8, LORA_SIN_PI_8);     // W16^9
+    {
+      dft4(u[0][0], u[1][0], u[2][0], u[3][0]);
+      x[0] = u[0][0]; x[4] = u[1][0]; x[8] = u[2][0]; x[12] = u[3][0];
+    }
+    {   // k1 = 1: W^1, W^2 = (1-j)/sqrt2, W^3
+      float2 a0, a1, a2, a3;
+      const float2 p1 = cmul(u[1][1], w1);
+      bfly_w8_1(u[0][1], u[2][1], a0, a1);
+      bfly_tw(p1, w3, u[3][1], a2, a3);
+      dft4_tail(a0, a1, a2, a3, x[1], x[5], x[9], x[13]);
+    }
+    {   // k1 = 2: W^2 = (1-j)/sqrt2, W^4 = -j, W^6 = (-1-j)/sqrt2
+      float2 a0, a1, a2, a3;
+      const float2 p1 = make_float2((u[1][2].x + u[1][2].y) * LORA_SQRT1_2, (u[1][2].y - u[1][2].x) * LORA_SQRT1_2);
+      const float2 b2 = mul_mj(u[2][2]);
+      a0 = cadd(u[0][2], b2); a1 = csub(u[0][2], b2);
+      bfly_w8_3(p1, u[3][2], a2, a3);
+      dft4_tail(a0, a1, a2, a3, x[2], x[6], x[10], x[14]);
+    }
+    {   // k1 = 3: W^3, W^6 = (-1-j)/sqrt2, W^9
+      float2 a0, a1, a2, a3;
+      const float2 p1 = cmul(u[1][3], w3);
+      bfly_w8_3(u[0][3], u[2][3], a0, a1);
+      bfly_tw(p1, w9, u[3][3], a2, a3);
+      dft4_tail(a0, a1, a2, a3, x[3], x[7], x[11], x[15]);
     }
   }
+  __device__ static __forceinline__ void run(float2 *x) { run_impl<false>(x, nullptr); }
+  __device__ static __forceinline__ void run_tw(float2 *x, const float2 *w) { run_impl<true>(x, w); }
 };
 
 // ---- geometry ---------------------------------------------------------------------------
@@ -181,6 +240,9 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #ifndef LORA_STAMPS
 #define LORA_STAMPS 0
 #endif
+#ifndef LORA_CLOCK
+#define LORA_CLOCK 0      // diagnostic build: every workgroup records s_memtime and s_memrealtime over its lifetime (in-kernel clock)
+#endif
 #if LORA_STAMPS
 #define LORA_STAMP_PARAMS , unsigned long long (&stamp_acc)[8], unsigned long long &stamp_last
 #define LORA_STAMP_ARGS , stamp_acc, stamp_last
@@ -189,6 +251,26 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #define LORA_STAMP_PARAMS
 #define LORA_STAMP_ARGS
 #define LORA_STAMP(i) do { } while (0)
+#endif
+// scheduling fence: the backend's scheduler otherwise stretches live ranges across phases (hoisted LDS reads and
+// twiddle powers) until the register budget spills
+#define LORA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef LORA_FENCES
+#define LORA_FENCES 0     // 1: fft_sf12 / demod_kernel<12> carry scheduling fences and form the twiddle powers right before use
+#endif
+#define LORA_FENCE1() do { if (LORA_FENCES) LORA_SCHED_FENCE(); } while (0)
+#ifndef LORA_TWPRE
+#define LORA_TWPRE 1      // pass twiddles that live in LDS are requested before the pass's barrier (their latency hides behind
+                          // the scatter drain and the barrier) instead of one by one between the multiplies
+#endif
+#ifndef LORA_SPREAD
+#define LORA_SPREAD 1     // SF12 sweep: the next window's IQ loads are spread over the last sub-transform as scalar-addressed buffer loads
+#endif
+#ifndef LORA_W4
+#define LORA_W4 0
+#endif
+#ifndef LORA_W4_KRES
+#define LORA_W4_KRES 8
 #endif
 #ifndef LORA_SF12_DIGITS
 #define LORA_SF12_DIGITS 1
@@ -263,6 +345,16 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
   static_assert(T % 16 == 0 || T == 8 || T == 4, "pad split: tw + k*T must not carry out of bit 3");
   static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
   LORA_STAMP(2);                     // compute (butterflies, scatter) since the last stamp
+  constexpr bool kTwPre = LORA_TWPRE && PS > 0 && pass_table_in_lds(LOGN, F, PS);
+  float2 tpre[kTwPre ? nb * (r - 1) : 1];
+  if constexpr (kTwPre) {            // this pass's twiddles (read-only LDS table): requested before the barrier
+#pragma unroll
+    for (int q = 0; q < nb; q++) {
+      const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + ((tw + q * T) & (NS - 1));
+#pragma unroll
+      for (int m = 1; m < r; m++) tpre[q * (r - 1) + m - 1] = tp[(m - 1) * NS];
+    }
+  }
   if constexpr (PS > 0) {
     LORA_PASS_BARRIER();             // previous pass's scatter is visible
     LORA_STAMP(5);                   // barrier wait
@@ -283,19 +375,22 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
     for (int m = 0; m < r; m++) a[m] = v[q + m * nb];
     if constexpr (PS > 0) {
       const int jm = j & (NS - 1);
+      float2 w[r];                   // w[m], m >= 1: this butterfly's pass twiddles
 #if LORA_ABL & 4
 #pragma unroll
-      for (int m = 1; m < r; m++) a[m] = cmul(a[m], make_float2(0.6f + m, 0.8f));
+      for (int m = 1; m < r; m++) w[m] = make_float2(0.6f + m, 0.8f);
 #else
-      if constexpr (pass_table_in_lds(LOGN, F, PS)) {
+      if constexpr (kTwPre) {
+#pragma unroll
+        for (int m = 1; m < r; m++) w[m] = tpre[q * (r - 1) + m - 1];
+      } else if constexpr (pass_table_in_lds(LOGN, F, PS)) {
         const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + jm;
 #pragma unroll
-        for (int m = 1; m < r; m++) a[m] = cmul(a[m], tp[(m - 1) * NS]);
+        for (int m = 1; m < r; m++) w[m] = tp[(m - 1) * NS];
       } else {
         // base twiddle of this butterfly from the caller's registers; every other power is a product
         static_assert(r == 8 || r == 16, "power chain covers radix 8 and 16");
         static_assert(last, "only the last pass has a table too big for LDS");
-        float2 w[16];
         w[1] = wb[q];
         asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));   // loop-invariant, but hoisted powers would cost 2r registers
         w[2] = csqr(w[1]); w[4] = csqr(w[2]);
@@ -305,12 +400,18 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
 #pragma unroll
           for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
         }
-#pragma unroll
-        for (int m = 1; m < r; m++) a[m] = cmul(a[m], w[m]);
       }
 #endif
+      if constexpr (r == 16) {
+        Dft<16>::run_tw(a, w);       // twiddles folded into the first butterflies
+      } else {
+#pragma unroll
+        for (int m = 1; m < r; m++) a[m] = cmul(a[m], w[m]);
+        Dft<r>::run(a);
+      }
+    } else {
+      Dft<r>::run(a);
     }
-    Dft<r>::run(a);
     if constexpr (!last) {
       const int o = (j / NS) * NS * r + (j & (NS - 1));
 #pragma unroll
@@ -337,24 +438,36 @@ constexpr int demod_lds_table_entries() { return pass_lds_offset(LOGN, F, plan_p
 // execute in order): two workgroup barriers per transform instead of four.  Rows are 272 = 16*17
 // elements long: conflict-free for the row-contiguous accesses of exchange 1 and for the
 // stride-17 transpose of exchange 2.
-template <int F>
+// hook(stage), stage 1..3: where the caller may issue a share of the next window's IQ loads (after the scatter, after
+// the pass-1 twiddles, behind the wave-local exchange), so that a wave never sits behind a burst of sixteen loads
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int F, typename Hook = NoHook>
 __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const float2 *lds_tw, const int tw,
-                                         const float2 w1, const int rr LORA_STAMP_PARAMS) {
+                                         const float2 w1_in, const int rr LORA_STAMP_PARAMS, const Hook &hook = Hook()) {
   static_assert(pass_table_in_lds(12, F, 1) && !pass_table_in_lds(12, F, 2), "table placement assumed below");
   constexpr int ROW = 272;
   const int hi = tw >> 4, lo = tw & 15;
   Dft<16>::run(v);                                   // n2 -> ka
 #if !(LORA_ABL & 32)
   LORA_STAMP(2);
-  __syncthreads();                                   // every wave is done with the previous transform's rows
+  if (!(LORA_ABL & 128)) __syncthreads();            // every wave is done with the previous transform's rows
   LORA_STAMP(5);
   {
     float2 *o = tile + tw;
 #pragma unroll
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
+#if LORA_TWPRE
+  float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
+  {
+    const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
+#pragma unroll
+    for (int m = 1; m < 16; m++) t1[m - 1] = tp[(m - 1) * 16];
+  }
+#endif
+  hook(1);
   LORA_STAMP(6);
-  __syncthreads();
+  if (!(LORA_ABL & 128)) __syncthreads();
   LORA_STAMP(5);
   {
     const float2 *i = tile + hi * ROW + lo;
@@ -363,14 +476,21 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   }
   LORA_STAMP(6);
 #endif
+  LORA_FENCE1();
   {
+#if !(LORA_TWPRE && !(LORA_ABL & 32))
+    float2 t1[15];
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
-    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tp[(m - 1) * 16]);
+    for (int m = 1; m < 16; m++) t1[m - 1] = tp[(m - 1) * 16];
+#endif
+    hook(2);
+    Dft<16>::run_tw(v, t1 - 1);                      // twiddles folded into the first butterflies; n1 -> kb
   }
-  Dft<16>::run(v);                                   // n1 -> kb
+  LORA_FENCE1();
+  LORA_FENCE1();
   LORA_STAMP(2);
-#if !(LORA_ABL & 32)
+#if !(LORA_ABL & (32 | 256))
   {
     float2 *o = tile + hi * ROW + lo;
 #pragma unroll
@@ -381,21 +501,20 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   }
   LORA_STAMP(6);
 #endif
+  hook(3);
   {
     // powers of this butterfly's base twiddle w1 = W_M^(F*g + rr), g = ka + 16*kb: w1 is a per-thread
     // constant of the whole launch (kept in registers by the caller), everything else is products,
     // so that the loop holds no vector load besides the IQ prefetch
     float2 w[16];
-    w[1] = w1;
+    w[1] = w1_in;
     asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));     // loop-invariant, but 30 registers of hoisted powers would spill
     w[2] = csqr(w[1]); w[4] = csqr(w[2]); w[8] = csqr(w[4]);
     w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
 #pragma unroll
     for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
-#pragma unroll
-    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], w[m]);
+    Dft<16>::run_tw(v, w);                           // twiddles folded in; n0 -> kc: v[kc] is bin g + 256*kc
   }
-  Dft<16>::run(v);                                   // n0 -> kc: v[kc] is bin g + 256*kc
 }
 
 // Everything the kernel needs to know about one window, resolved one iteration ahead.
@@ -405,13 +524,15 @@ struct WinCtx {
   bool valid, in_range;
 };
 
-template <int N>
+// STRIDED: the launch has no descriptor list (known at compile time for the register-resident-taps kernels, which keeps
+// descriptor loads and their waits out of the steady-state loop)
+template <int N, bool STRIDED = false>
 __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned win_id) {
   WinCtx c;
   c.win_id = win_id;
   c.valid = win_id < p.n_win;
   unsigned off, kind;
-  if (p.desc != nullptr) {
+  if (!STRIDED && p.desc != nullptr) {
     const WinDesc d = c.valid ? reinterpret_cast<const WinDesc *>(p.desc)[win_id] : WinDesc{0, 0, 0, {0}};
     c.pos = d.pos; off = d.off; kind = d.kind;
   } else {
@@ -478,6 +599,9 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     }
   }
 
+#if LORA_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #if LORA_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
@@ -571,7 +695,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   }
   __syncthreads();                 // the LDS twiddle tables and the ring are visible
   unsigned cur_g = kWaveLocal ? blockIdx.x * kWorkers + wave : blockIdx.x;
-  WinCtx cur = window_ctx<N>(p, cur_g * GW + wig);
+  WinCtx cur = window_ctx<N, CONST_OFF>(p, cur_g * GW + wig);
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
   // (taps = chirp x Kaiser window, multiplied once: see the dechirp below)
   float2 cc[CONST_OFF ? R : 1];
@@ -579,7 +703,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     const float2 *__restrict__ chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
     const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
-    for (int k = 0; k < R; k++) {
+    for (int k = 0; k < ((LORA_W4 && LOGN == 12 && !ANYF) ? LORA_W4_KRES : R); k++) {
       const float2 ck = chirp[k * T];
       const float wk = (p.kind == 0) ? wsrc[k * T] : 1.0f;     // the SFD path has no window (:310)
       cc[k] = make_float2(ck.x * wk, ck.y * wk);
@@ -608,6 +732,23 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #pragma unroll
     for (int k = 0; k < R; k++) nx[k] = src[k * T];
   }
+  // LORA_W4 (SF12 steady-state sweep at four waves per SIMD, 128 registers): only the first KRES taps of a thread stay in
+  // registers; the chirp and window values of the others are fetched again (from L2) for every window, at the end of
+  // the previous one, when the transform's registers are free.  Same products, bit-identical results.
+  constexpr bool kW4 = LORA_W4 && CONST_OFF && LOGN == 12 && !ANYF;
+  constexpr int KRES = kW4 ? LORA_W4_KRES : R;
+  float2 cl_c[kW4 ? R - KRES : 1];
+  float cl_w[kW4 ? R - KRES : 1];
+  auto reload_taps = [&]() {
+    if constexpr (kW4) {
+      const float2 *chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
+      const float *wsrc = p.win + tw;
+      asm volatile("" : "+v"(chirp), "+v"(wsrc));      // not loop-invariant as far as the compiler can tell
+#pragma unroll
+      for (int k = KRES; k < R; k++) { cl_c[k - KRES] = chirp[k * T]; cl_w[k - KRES] = wsrc[k * T]; }
+    }
+  };
+  reload_taps();
   // The store of window i is deferred into window i + 1 when the window spans several waves (the partials
   // meet behind the next window's barriers) and, measured, whenever F > 1; at F = 1 with a window inside one
   // wave storing at once frees the registers of the deferred state (SF7/SF8: +28 % / +41 %).
@@ -620,11 +761,17 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 
   for (unsigned it = 0; cur_g < n_groups; it++) {
     LORA_STAMP(0);
-    unsigned tk = 0;
-    if (drawer) tk = atomicAdd(my_ticket, 1u);        // G(it + LOOK) (wave-local: G(it + 2)); lands while this group is processed
     // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
     float2 c[R];
-    if constexpr (CONST_OFF) {
+    if constexpr (kW4) {
+#pragma unroll
+      for (int k = 0; k < KRES; k++) c[k] = cc[k];
+#pragma unroll
+      for (int k = KRES; k < R; k++) {
+        const float wk = (p.kind == 0) ? cl_w[k - KRES] : 1.0f;
+        c[k] = make_float2(cl_c[k - KRES].x * wk, cl_c[k - KRES].y * wk);
+      }
+    } else if constexpr (CONST_OFF) {
 #pragma unroll
       for (int k = 0; k < R; k++) c[k] = cc[k];
     } else {
@@ -645,10 +792,10 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     WinCtx nxt;
     if constexpr (kWaveLocal) {
       nxt_g = n_workers + __builtin_amdgcn_readfirstlane(tk1) * kQueues + my_queue;   // drawn one iteration ago
-      nxt = window_ctx<N>(p, nxt_g * GW + wig);
+      nxt = window_ctx<N, CONST_OFF>(p, nxt_g * GW + wig);
     } else if constexpr (!kLateRead) {
       nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);   // G(it + 1); uniform: scalar window arithmetic
-      nxt = window_ctx<N>(p, nxt_g * GW + wig);
+      nxt = window_ctx<N, CONST_OFF>(p, nxt_g * GW + wig);
     }
 
     // ---- dechirp + window: x[k] <-> sample n = tw + k*T -----------------------------------
@@ -661,7 +808,21 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
       // magnitude inside the 1e-4 bar (measured agreement with the oracle: profiles/r01_v13_accuracy.txt)
       x[k] = cmul(nx[k], c[k]);
     }
+    LORA_FENCE1();
     LORA_STAMP(1);    // operands landed + dechirp
+    // G(it + LOOK) (wave-local: G(it + 2)); lands while this group is processed.  Drawn behind the dechirp: in vmcnt order
+    // a wait for the last IQ load would otherwise also be a wait for this atomic
+    unsigned tk = 0;
+    {
+      static_assert(R <= 16, "asm operand count");
+      // every IQ load has been waited for once all of x exists; only then may the atomic be issued
+      if constexpr (R == 16)
+        asm volatile("" :: "v"(x[0].x), "v"(x[1].x), "v"(x[2].x), "v"(x[3].x), "v"(x[4].x), "v"(x[5].x), "v"(x[6].x), "v"(x[7].x),
+                     "v"(x[8].x), "v"(x[9].x), "v"(x[10].x), "v"(x[11].x), "v"(x[12].x), "v"(x[13].x), "v"(x[14].x), "v"(x[15].x));
+      else
+        asm volatile("" :: "v"(x[0].x), "v"(x[1].x), "v"(x[2].x), "v"(x[3].x), "v"(x[4].x), "v"(x[5].x), "v"(x[6].x), "v"(x[7].x));
+    }
+    if (drawer) tk = atomicAdd(my_ticket, 1u);
 
     Best best = {-1.0f, 0};
     bool bin0_nan = false;
@@ -681,6 +842,8 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #pragma unroll
         for (int k = 0; k < R; k++) v[k] = mul_w64(x[k], rr * k * (64 / (F * R)));   // W_M^(rr*k*T)
       }
+      LORA_FENCE1();
+      constexpr bool kSpread = LORA_SPREAD && kDigits && CONST_OFF && !ANYF;     // SF12 steady-state sweep
       if (!ANYF && rr == F - 1) {
         // x is dead from here on: prefetch the next window's raw IQ, a whole sub-transform early
         // (any-factor kernels: the compiler cannot see that in a run-time loop, x and nx would both stay
@@ -688,20 +851,49 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
         asm volatile("" ::: "memory");
         if constexpr (kLateRead) {
           nxt_g = __builtin_amdgcn_readfirstlane(ring[(it + 1) % LOOK]);
-          nxt = window_ctx<N>(p, nxt_g * GW + wig);
+          nxt = window_ctx<N, CONST_OFF>(p, nxt_g * GW + wig);
         }
-        const float2 *__restrict__ src = p.iq + ((LORA_ABL & 64) ? 0 : nxt.pos) + tw;   // ABL 64: every window reads window 0 (L2)
+        if constexpr (!kSpread) {
+          const float2 *__restrict__ src = p.iq + ((LORA_ABL & 64) ? 0 : nxt.pos) + tw;   // ABL 64: every window reads window 0 (L2)
 #pragma unroll
-        for (int k = 0; k < R; k++) {
+          for (int k = 0; k < R; k++) {
 #if LORA_ABL & 1
-          nx[k] = make_float2(1.0f + tw, k);
+            nx[k] = make_float2(1.0f + tw, k);
 #else
-          nx[k] = src[k * T];
+            nx[k] = src[k * T];
 #endif
+          }
         }
       }
+      // kSpread: the sixteen loads of a thread go out in four groups along the last sub-transform, as buffer loads: one
+      // scalar descriptor per window (base = first sample of the window, 8N bytes), the lane's byte offset in one VGPR, the
+      // register index in the scalar offset -- no vector address arithmetic at all
+      buf_rsrc_t pf_rsrc;
+      {
+        // the window position is wave-uniform (T >= 64): say so, or every load is wrapped in a waterfall loop
+        const unsigned long long a = (unsigned long long)(p.iq + ((kSpread && rr == F - 1) ? nxt.pos : 0ull));
+        pf_rsrc.x = __builtin_amdgcn_readfirstlane((int)a);
+        pf_rsrc.y = __builtin_amdgcn_readfirstlane((int)(a >> 32)) & 0xffff;       // stride 0
+        pf_rsrc.z = N * (int)sizeof(float2);                                          // bytes: loads past the window return 0
+        pf_rsrc.w = 0x00020000;                                                       // raw 32-bit data format
+      }
+      constexpr int kPfGroups = (LORA_SPREAD == 2 || (LORA_SPREAD == 3 && F > 1)) ? 1 : 4;   // 1: all sixteen at stage 0
+      auto pf_issue = [&](const int g) {
+        if constexpr (kSpread) {
+          if (rr == F - 1 && g < kPfGroups) {
+            LORA_SCHED_FENCE();
+#pragma unroll
+            for (int k = (R / kPfGroups) * g; k < (R / kPfGroups) * (g + 1); k++) {
+              const buf_v2f_t d = buffer_load_v2f32(pf_rsrc, tw * (int)sizeof(float2), k * T * (int)sizeof(float2), 0);
+              nx[k] = make_float2(d.x, d.y);
+            }
+            LORA_SCHED_FENCE();
+          }
+        }
+      };
+      pf_issue(0);
       const int trr = ANYF ? 0 : rr;                // row of the twiddle tables: the any-factor twist is already in v
-      if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[trr], trr LORA_STAMP_ARGS);
+      if constexpr (kDigits) fft_sf12<F>(v, tile, lds_tw, tw, wb[trr], trr LORA_STAMP_ARGS, pf_issue);
       else fft_pass<LOGN, F, 0, 1>(v, tile, lds_tw, tw, wb + (kBaseRegs ? trr * NBL : 0), trr LORA_STAMP_ARGS);
       LORA_STAMP(2);  // all passes of this sub-transform
       if constexpr (kDeferStore) {
@@ -724,9 +916,11 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #endif
       }
       best = (rr == 0) ? b : better(best, b);
+      LORA_FENCE1();
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
       asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
     }
+    reload_taps();
     if constexpr (ANYF) {
       const float2 *__restrict__ src = p.iq + nxt.pos + tw;
 #pragma unroll
@@ -738,6 +932,11 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     } else {
       combine_store(cur, reduce_partial(best, par), bin0_nan, par);   // a window inside one wave is final already
     }
+    // The ticket is first touched here: the compiler must not form anything from it at the draw (it sinks such arithmetic
+    // into the drawing branch, and the wait for the atomic -- which in vmcnt order is also a wait for the IQ prefetch --
+    // would then stall thread 0's wave for an atomic round trip at the top of every iteration, with the workgroup's
+    // other waves waiting for it at the next barrier).  Built with -amdgpu-atomic-optimizer-strategy=None for the same reason.
+    asm volatile("" : "+v"(tk));
     if constexpr (kWaveLocal) tk1 = tk;
     else if (drawer) ring[it % LOOK] = n_workers + tk * kQueues + my_queue;   // read LOOK - 1 iterations from now, behind barriers
     cur = nxt; cur_g = nxt_g;
@@ -747,6 +946,12 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     if (T > 64) __syncthreads();
     combine_store(prev, prev_best, prev_nan, par ^ 1);
   }
+#if LORA_CLOCK
+  if (p.dbg && tid == 0) {
+    p.dbg[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_t0;
+    p.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
 #if LORA_STAMPS
   stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
   if (p.dbg && (tid & 63) == 0) {
