@@ -47,6 +47,25 @@ struct KParams {
 
 struct WinDesc { unsigned long long pos; unsigned short off; unsigned char kind; unsigned char pad[5]; };
 
+// One ds_read_b64 per call.  The backend otherwise pairs LDS reads into ds_read2_b64, which moves its 1 KiB per wave in 8
+// LDS cycles where two ds_read_b64 take 2 + 2 (MI355X_MICROARCH.md, LDS table): the exchanges of the FFT are the
+// LDS's main load (measured: LDS array busy 48 % of the kernel with read2, SQ_WAIT_INST_LDS 19 % of wave cycles).
+// A volatile access is never merged; the reads keep their program order, which is the order they are written in.
+// Measured per spreading factor: SF12 +3-4 %, SF9 +2 %, SF11 none, SF6-SF8 and SF10 -1 % (the fixed order costs the
+// small windows more than the LDS cycles gain them), hence lds_single().
+constexpr bool lds_single(int logn) { return logn == 9 || logn >= 11; }
+template <bool SINGLE>
+__device__ __forceinline__ float2 lds_read(const float2 *p) {
+  if constexpr (SINGLE) {
+    typedef float lds_v2f __attribute__((ext_vector_type(2)));
+    typedef const volatile __attribute__((address_space(3))) lds_v2f *lds_ptr_t;      // LDS, not a flat access
+    const lds_v2f t = *(lds_ptr_t)(p);
+    return make_float2(t.x, t.y);
+  } else {
+    return *p;
+  }
+}
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // complex multiply of the FFT (twiddles): explicit FMA form so that every kernel that shares this
@@ -263,6 +282,10 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #define LORA_TWPRE 1      // pass twiddles that live in LDS are requested before the pass's barrier (their latency hides behind
                           // the scatter drain and the barrier) instead of one by one between the multiplies
 #endif
+#ifndef LORA_KTRACK
+#define LORA_KTRACK 0     // 1: the per-thread argmax scan tracks the register index only (fewer instructions, but measured
+                          // neutral, and the allocator spills in several variants)
+#endif
 #ifndef LORA_SPREAD
 #define LORA_SPREAD 1     // SF12 sweep: the next window's IQ loads are spread over the last sub-transform as scalar-addressed buffer loads
 #endif
@@ -275,14 +298,21 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #ifndef LORA_SF12_DIGITS
 #define LORA_SF12_DIGITS 1
 #endif
+#ifndef LORA_F1_W4
+#define LORA_F1_W4 0      // 1: fft_factor 1 at SF10-SF12 is cut for four waves per SIMD (128 registers)
+#endif
 #ifndef LORA_MIN_WAVES
 #define LORA_MIN_WAVES 3
 #endif
 // Waves per SIMD the register budget is cut for.  SF9 keeps 8 points per thread (72-127 VGPRs), so it can run
 // six (F <= 2) or four (F = 4) instead of three: measured +17 % at F = 2, nothing at F = 1 (memory-bound).
 constexpr int min_waves(int logn, int f) {
-  return (LORA_SF12_R8 && logn == 12) ? 4 : (logn == 9) ? (f <= 2 ? 6 : 4) : LORA_MIN_WAVES;
+  return (LORA_SF12_R8 && logn == 12) ? 4 : (logn == 9) ? (f <= 2 ? 6 : 4) : (LORA_F1_W4 && f == 1 && logn >= 10) ? 4 : LORA_MIN_WAVES;
 }
+
+// Requesting a pass's LDS twiddles before its barrier keeps up to 30 more registers live across it: only where the
+// variant's register budget takes that without spilling (checked with -Rpass-analysis=kernel-resource-usage)
+constexpr bool twpre_fits(int logn, int f) { return f <= 2 && logn != 9 && logn != 11; }
 
 // Twiddle table of pass ps >= 1 (merged with the zero-padding twist, see fft_pass).  Vector loads
 // return to the registers at only ~32 B/clk per CU (measured: TD busy 84 % with tables in L2), so
@@ -345,21 +375,21 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
   static_assert(T % 16 == 0 || T == 8 || T == 4, "pad split: tw + k*T must not carry out of bit 3");
   static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
   LORA_STAMP(2);                     // compute (butterflies, scatter) since the last stamp
-  constexpr bool kTwPre = LORA_TWPRE && PS > 0 && pass_table_in_lds(LOGN, F, PS);
+  constexpr bool kTwPre = LORA_TWPRE && twpre_fits(LOGN, F) && PS > 0 && pass_table_in_lds(LOGN, F, PS);
   float2 tpre[kTwPre ? nb * (r - 1) : 1];
   if constexpr (kTwPre) {            // this pass's twiddles (read-only LDS table): requested before the barrier
 #pragma unroll
     for (int q = 0; q < nb; q++) {
       const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + ((tw + q * T) & (NS - 1));
 #pragma unroll
-      for (int m = 1; m < r; m++) tpre[q * (r - 1) + m - 1] = tp[(m - 1) * NS];
+      for (int m = 1; m < r; m++) tpre[q * (r - 1) + m - 1] = lds_read<lds_single(LOGN)>(&tp[(m - 1) * NS]);
     }
   }
   if constexpr (PS > 0) {
     LORA_PASS_BARRIER();             // previous pass's scatter is visible
     LORA_STAMP(5);                   // barrier wait
 #pragma unroll
-    for (int k = 0; k < R; k++) v[k] = tile[lds_pad(tw) + lds_pad(k * T)];
+    for (int k = 0; k < R; k++) v[k] = lds_read<lds_single(LOGN)>(&tile[lds_pad(tw) + lds_pad(k * T)]);
     LORA_STAMP(6);                   // LDS gather latency
     if constexpr (!last) LORA_PASS_BARRIER();   // everyone has read before the tile is overwritten
     LORA_STAMP(5);
@@ -386,7 +416,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
       } else if constexpr (pass_table_in_lds(LOGN, F, PS)) {
         const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + jm;
 #pragma unroll
-        for (int m = 1; m < r; m++) w[m] = tp[(m - 1) * NS];
+        for (int m = 1; m < r; m++) w[m] = lds_read<lds_single(LOGN)>(&tp[(m - 1) * NS]);
       } else {
         // base twiddle of this butterfly from the caller's registers; every other power is a product
         static_assert(r == 8 || r == 16, "power chain covers radix 8 and 16");
@@ -457,14 +487,13 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
 #pragma unroll
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
-#if LORA_TWPRE
+  constexpr bool kTwPre12 = LORA_TWPRE && twpre_fits(12, F) && !(LORA_ABL & 32);
   float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
-  {
+  if constexpr (kTwPre12) {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
-    for (int m = 1; m < 16; m++) t1[m - 1] = tp[(m - 1) * 16];
+    for (int m = 1; m < 16; m++) t1[m - 1] = lds_read<lds_single(12)>(&tp[(m - 1) * 16]);
   }
-#endif
   hook(1);
   LORA_STAMP(6);
   if (!(LORA_ABL & 128)) __syncthreads();
@@ -472,18 +501,17 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   {
     const float2 *i = tile + hi * ROW + lo;
 #pragma unroll
-    for (int m = 0; m < 16; m++) v[m] = i[m * 16];   // thread (ka = hi, n0 = lo), register n1 = m
+    for (int m = 0; m < 16; m++) v[m] = lds_read<lds_single(12)>(&i[m * 16]);   // thread (ka = hi, n0 = lo), register n1 = m
   }
   LORA_STAMP(6);
 #endif
   LORA_FENCE1();
   {
-#if !(LORA_TWPRE && !(LORA_ABL & 32))
-    float2 t1[15];
-    const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
+    if constexpr (!kTwPre12) {
+      const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
-    for (int m = 1; m < 16; m++) t1[m - 1] = tp[(m - 1) * 16];
-#endif
+      for (int m = 1; m < 16; m++) t1[m - 1] = lds_read<lds_single(12)>(&tp[(m - 1) * 16]);
+    }
     hook(2);
     Dft<16>::run_tw(v, t1 - 1);                      // twiddles folded into the first butterflies; n1 -> kb
   }
@@ -497,7 +525,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     for (int m = 0; m < 16; m++) o[m * 17] = v[m];   // own row: [kb = m][n0 = lo], wave-local
     const float2 *i = tile + hi * ROW + lo * 17;
 #pragma unroll
-    for (int m = 0; m < 16; m++) v[m] = i[m];        // thread (ka = hi, kb = lo), register n0 = m
+    for (int m = 0; m < 16; m++) v[m] = lds_read<lds_single(12)>(&i[m]);        // thread (ka = hi, kb = lo), register n0 = m
   }
   LORA_STAMP(6);
 #endif
@@ -614,30 +642,39 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   // The two red[] halves alternate, so a half is rewritten two windows later, behind barriers.
   auto reduce_partial = [&](Best best, const int par) -> Best {
     constexpr int LANES = T < 64 ? T : 64;
-    // DPP cross-lane steps (VALU data path, a few cycles each) instead of ds_bpermute shuffles (~100
-    // cycles each, 12 of them in a dependent chain per window)
-#define LORA_DPP_STEP(ctrl, row_mask)                                                                         \
-    {                                                                                                         \
-      Best o;                                                                                                 \
-      o.v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, best.v),            \
-                                                                  __builtin_bit_cast(int, best.v), ctrl, row_mask, 0xF, false)); \
-      o.i = __builtin_amdgcn_update_dpp(best.i, best.i, ctrl, row_mask, 0xF, false);                          \
-      best = better(best, o);                                                                                 \
-    }
+    // DPP cross-lane steps (VALU data path, a few cycles each) instead of ds_bpermute shuffles (~100 cycles each).
+    // |X|^2 is never negative and never NaN here (a NaN never wins the per-thread scan), so the float order is the
+    // order of the bit patterns as integers (the initial -1 sorts below everything): first the maximum by integer max
+    // steps, then the lowest index among the lanes that hold it by integer min steps -- demod_impl::argmax's
+    // lowest-bin rule (:123-131), in 2 instructions per step instead of 9 for a (value, index) pair.
+    int vb = __builtin_bit_cast(int, best.v);
+    const int own = vb;
+#define LORA_DPP_MAX(ctrl, row_mask) { const int o = __builtin_amdgcn_update_dpp(vb, vb, ctrl, row_mask, 0xF, false); vb = o > vb ? o : vb; }
+#define LORA_DPP_MIN(ctrl, row_mask) { const int o = __builtin_amdgcn_update_dpp(ci, ci, ctrl, row_mask, 0xF, false); ci = o < ci ? o : ci; }
     if (!(LORA_ABL & 8)) {
-      if (LANES >= 2) LORA_DPP_STEP(0xB1, 0xF)      // quad_perm [1,0,3,2]: lane ^ 1
-      if (LANES >= 4) LORA_DPP_STEP(0x4E, 0xF)      // quad_perm [2,3,0,1]: lane ^ 2
-      if (LANES >= 8) LORA_DPP_STEP(0x141, 0xF)     // row_half_mirror: every lane of 8 has the best of 8
-      if (LANES >= 16) LORA_DPP_STEP(0x140, 0xF)    // row_mirror: every lane of a row has the row's best
-      if (LANES >= 32) LORA_DPP_STEP(0x142, 0xA)    // row_bcast:15 into rows 1 and 3
-      if (LANES >= 64) LORA_DPP_STEP(0x143, 0xC)    // row_bcast:31 into rows 2 and 3: lane 63 has the wave's best
+      if (LANES >= 2) LORA_DPP_MAX(0xB1, 0xF)      // quad_perm [1,0,3,2]: lane ^ 1
+      if (LANES >= 4) LORA_DPP_MAX(0x4E, 0xF)      // quad_perm [2,3,0,1]: lane ^ 2
+      if (LANES >= 8) LORA_DPP_MAX(0x141, 0xF)     // row_half_mirror: every lane of 8 has the best of 8
+      if (LANES >= 16) LORA_DPP_MAX(0x140, 0xF)    // row_mirror: every lane of a row has the row's best
+      if (LANES >= 32) LORA_DPP_MAX(0x142, 0xA)    // row_bcast:15 into rows 1 and 3
+      if (LANES >= 64) LORA_DPP_MAX(0x143, 0xC)    // row_bcast:31 into rows 2 and 3: lane 63 has the wave's best
     }
-#undef LORA_DPP_STEP
-    if (LANES == 64) {
-      // the wave's result sits in lane 63; make it uniform (two v_readlane)
-      best.v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best.v), 63));
-      best.i = __builtin_amdgcn_readlane(best.i, 63);
+    static_assert(LANES <= 16 || LANES == 64, "a 32-lane group would leave its result in the upper row only");
+    if (LANES == 64) vb = __builtin_amdgcn_readlane(vb, 63);          // uniform
+    int ci = (own == vb) ? best.i : 0x7fffffff;
+    if (!(LORA_ABL & 8)) {
+      if (LANES >= 2) LORA_DPP_MIN(0xB1, 0xF)
+      if (LANES >= 4) LORA_DPP_MIN(0x4E, 0xF)
+      if (LANES >= 8) LORA_DPP_MIN(0x141, 0xF)
+      if (LANES >= 16) LORA_DPP_MIN(0x140, 0xF)
+      if (LANES >= 32) LORA_DPP_MIN(0x142, 0xA)
+      if (LANES >= 64) LORA_DPP_MIN(0x143, 0xC)
     }
+#undef LORA_DPP_MAX
+#undef LORA_DPP_MIN
+    if (LANES == 64) ci = __builtin_amdgcn_readlane(ci, 63);
+    best.v = __builtin_bit_cast(float, vb);
+    best.i = ci;
     if (T > 64) {
       if ((tid & 63) == 0) red[par * (kBlock / 64) + tid / 64] = best;
     }
@@ -900,21 +937,21 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
         if (rr == 0 && have_prev) combine_store(prev, prev_best, prev_nan, par ^ 1);   // previous window, behind barriers
       }
       LORA_STAMP(4);
-      // last pass left bin kout = tw + k*T in v[k]; scan k upwards so that strict '>' keeps the
-      // lowest index of this thread's maximum for this rr
+      // last pass left bin kout = tw + k*T in v[k] (SF12 digit mapping: (tw>>4) + 16*(tw&15) + 256*k); scan k upwards so
+      // that strict '>' keeps the lowest index of this thread's maximum for this rr; only k is tracked in the scan
       Best b = {-1.0f, 0};
+      const int kbase = kDigits ? ((tw >> 4) + 16 * (tw & 15)) : tw, kstep = kDigits ? 256 : T;
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const float mag = magsq(v[k]);
         if (rr == 0 && k == 0 && tw == 0) bin0_nan = (mag != mag);      // thread 0 holds bin 0 in both mappings
-        // bin held by register k: generic Stockham tw + k*T; SF12 digit mapping (tw>>4) + 16*(tw&15) + 256*k
-        const int kout = kDigits ? ((tw >> 4) + 16 * (tw & 15) + 256 * k) : (tw + k * T);
 #if LORA_ABL & 16
         b.v += mag;
 #else
-        if (mag > b.v) { b.v = mag; b.i = FR * kout + rr; }
+        if (mag > b.v) { b.v = mag; b.i = LORA_KTRACK ? k : FR * (kbase + kstep * k) + rr; }
 #endif
       }
+      if (LORA_KTRACK) b.i = FR * (kbase + kstep * b.i) + rr;         // bin FR*kout + rr of the padded spectrum
       best = (rr == 0) ? b : better(best, b);
       LORA_FENCE1();
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
