@@ -35,6 +35,8 @@ EXPORTS = (
     "lora_hip_chan_last_hip_error", "lora_hip_chan_reset", "lora_hip_chan_output_count", "lora_hip_chan_work",
     "lora_hip_chan_taps_per_filter", "lora_hip_chan_dec_rate", "lora_hip_chan_flt_rate", "lora_hip_chan_kernel_name",
     "lora_hip_chan_force_general", "lora_hip_chan_phase_inc_effective", "lora_hip_chan_seek",
+    # include/lora_decode.h
+    "lora_decode_max_bytes", "lora_decode_pdu",
 )
 
 PDU_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint16), C.c_size_t)
@@ -114,6 +116,8 @@ def lib():
     L.lora_hip_chan_force_general.argtypes = [vp, i]; L.lora_hip_chan_force_general.restype = i
     L.lora_hip_chan_phase_inc_effective.argtypes = [vp]; L.lora_hip_chan_phase_inc_effective.restype = d
     L.lora_hip_chan_seek.argtypes = [vp, u64, vp, u]; L.lora_hip_chan_seek.restype = i
+    L.lora_decode_max_bytes.argtypes = [sz]; L.lora_decode_max_bytes.restype = sz
+    L.lora_decode_pdu.argtypes = [u, u, i, vp, sz, vp, sz, vp, sz, C.POINTER(sz)]; L.lora_decode_pdu.restype = i
     _lib = L
     return L
 

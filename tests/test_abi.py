@@ -21,10 +21,10 @@ def g():
 
 def declared_symbols():
     names = []
-    for h in ("lora_hip_demod.h", "lora_demod_core.h", "lora_hip_chan.h"):
+    for h in ("lora_hip_demod.h", "lora_demod_core.h", "lora_hip_chan.h", "lora_decode.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        names += re.findall(r"LORA_HIP_API\s+[^;(]*?\b(lora_\w+)\s*\(", txt)
+        names += re.findall(r"LORA_(?:HIP|DECODE)_API\s+[^;(]*?\b(lora_\w+)\s*\(", txt)
     return names
 
 

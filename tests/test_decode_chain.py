@@ -1,0 +1,139 @@
+"""The PDU decode chain (include/lora_decode.h) against the oracle's statement-by-statement restatement of
+lib/decode_impl.cc, on the CPU.  PARITY UNPINNED: the reference holds no vectors for its decode block
+(python/qa_decode.py:34-37 is an empty stub); the reference's whitening tables are read from its header at test time
+where /root/reference exists and are never stored here -- only decoded bytes are (tests/golden/decode_golden.json)."""
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TABLES = "/root/reference/include/lora/lora.h"
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gr_lora_amd
+    return gr_lora_amd
+
+
+@pytest.fixture(scope="module")
+def codec():
+    from oracle import codec_oracle
+    return codec_oracle
+
+
+def reference_whitening(sf, ldr):
+    """The reference's sequence for (sf, ldr) as lib/decode_impl.cc:72-113 picks it; None where the reference is absent."""
+    if not os.path.exists(REF_TABLES):
+        return None
+    name = f"whitening_sequence_sf{sf}_{'ldr_' if ldr else ''}implicit"
+    for line in open(REF_TABLES):
+        m = re.match(r"\s*const unsigned short " + name + r"\[\d+\]\s*=\s*\{(.*)\};", line)
+        if m:
+            return np.array([int(v, 0) for v in m.group(1).split(",") if v.strip()], np.uint16)
+    return None
+
+
+def synthetic_whitening(sf, seed):
+    return np.random.default_rng(seed).integers(0, 1 << sf, 400).astype(np.uint16)
+
+
+@pytest.mark.parametrize("sf", range(6, 13))
+@pytest.mark.parametrize("ldr", [False, True])
+def test_c_abi_equals_restatement(sf, ldr, g, codec):
+    rng = np.random.default_rng(100 * sf + ldr)
+    w = synthetic_whitening(sf, sf)
+    for cr in (1, 2, 3, 4):
+        d = g.decode(sf, cr, ldr, False, whitening_sequence=w)
+        for n in (0, 1, 7, 8, 9, 8 + 4 + cr - 1, 8 + 4 + cr, 8 + 3 * (4 + cr) + 2, 150, 300, 500):
+            s = rng.integers(0, 1 << sf, n).astype(np.uint16)
+            assert bytes(d.work(s)) == codec.decode_pdu(sf, cr, ldr, w, s.tolist()), (sf, ldr, cr, n)
+        # without a sequence: no de-whitening at all
+        s = rng.integers(0, 1 << sf, 64).astype(np.uint16)
+        assert bytes(g.decode(sf, cr, ldr).work(s)) == codec.decode_pdu(sf, cr, ldr, None, s.tolist())
+
+
+@pytest.mark.parametrize("ldr", [False, True])
+def test_encode_decode_round_trip_sf8(ldr, g, codec):
+    """txrx_sim.grc's setting (SF8, CR 4; examples/txrx_sim.grc:131-216): bytes -> restated encode -> decode gives the bytes
+    back wherever the reference's own chain is lossless (whole interleaver blocks; its encoder only fills ppm 6 and 8)."""
+    rng = np.random.default_rng(8 + ldr)
+    w = synthetic_whitening(8, 88)
+    w[:] &= 0xFF                                       # the encoder whitens 8-bit symbols (encode_impl.cc:158)
+    if ldr:
+        w[:] &= 0x3F                                   # 6-bit symbols throughout
+    else:
+        w[:8] &= 0x3F                                  # header symbols carry sf - 2 bits
+    # header: 6 nybbles (sf - 2); payload blocks of ppm nybbles: choose whole blocks
+    ppm = 6 if ldr else 8
+    n_bytes = (6 + 5 * ppm) // 2
+    data = rng.integers(0, 256, n_bytes).astype(np.uint8)
+    sym = codec.encode_pdu(8, 4, ldr, w, data.tolist())
+    # what the demod hands over: header symbols / 4, payload symbols / 4 under LDR (lib/demod_impl.cc:385,:404-411)
+    pdu = [s >> 2 if (i < 8 or ldr) else s for i, s in enumerate(sym)]
+    out = g.decode(8, 4, ldr, whitening_sequence=w).work(np.array(pdu, np.uint16))
+    assert bytes(out) == codec.decode_pdu(8, 4, ldr, w, pdu)
+    bad = list(pdu); bad[10] ^= 0x04                   # one corrupted bit per codeword: corrected by the (8,4) code at rdd 4
+    out_bad = g.decode(8, 4, ldr, whitening_sequence=w).work(np.array(bad, np.uint16))
+    assert bytes(out_bad) == bytes(out)
+    if ldr:
+        assert bytes(out) == bytes(data)               # the shipped flowgraph's setting (ldr True) is the lossless one
+    else:
+        # a reference quirk, reproduced: at ppm 8 its encoder places codewords c0..c7 at interleaver rows 0,7,2,1,4,3,6,5
+        # (encode_impl.cc:217-226) and its decoder reads rows 6,7,4,5,2,3,0,1 (decode_impl.cc:243-249), so within every
+        # payload block of 8 nybbles the loopback returns c6,c1,c4,c7,c2,c5,c0,c3; the header (ppm 6) is exact
+        nyb = [v for b in data for v in ((b & 0xF0) >> 4, b & 0x0F)]
+        exp = nyb[:6]
+        for k in range(6, len(nyb), 8):
+            blk = nyb[k:k + 8]
+            exp += [blk[i] for i in (6, 1, 4, 7, 2, 5, 0, 3)]
+        assert bytes(out) == bytes((exp[i] << 4) | exp[i + 1] for i in range(0, len(exp), 2))
+
+
+def test_argument_checks(g):
+    import ctypes as C
+    L = g.capi.lib()
+    n = C.c_size_t(0)
+    out = np.zeros(64, np.uint8)
+    s = np.zeros(20, np.uint16)
+    assert L.lora_decode_pdu(5, 4, 0, None, 0, s.ctypes.data, 20, out.ctypes.data, 64, C.byref(n)) == -1
+    assert L.lora_decode_pdu(8, 0, 0, None, 0, s.ctypes.data, 20, out.ctypes.data, 64, C.byref(n)) == -1
+    assert L.lora_decode_pdu(8, 5, 0, None, 0, s.ctypes.data, 20, out.ctypes.data, 64, C.byref(n)) == -1
+    assert L.lora_decode_pdu(8, 4, 0, None, 0, None, 20, out.ctypes.data, 64, C.byref(n)) == -1
+    assert L.lora_decode_pdu(8, 4, 0, None, 0, s.ctypes.data, 20, out.ctypes.data, 1, C.byref(n)) == -2 and n.value > 1
+    assert L.lora_decode_pdu(8, 4, 0, None, 0, s.ctypes.data, 20, out.ctypes.data, 64, C.byref(n)) == 0
+    with pytest.raises(ValueError):
+        g.decode(13, 4)
+    with pytest.raises(ValueError):
+        g.decode(8, 0)
+
+
+def golden_cases():
+    rng = np.random.default_rng(2024)
+    for sf in range(6, 13):
+        for ldr in (False, True):
+            for cr in (1, 4):
+                yield sf, ldr, cr, rng.integers(0, 1 << sf, 8 + 6 * (4 + cr) + 3).astype(np.uint16)
+
+
+def test_reference_tables_golden(g, codec):
+    """With the reference's own whitening tables (read from its header, where present): decoded bytes equal the
+    committed digests, for the C ABI and for the restatement.  Regenerate with LORA_WRITE_GOLDEN=1."""
+    if not os.path.exists(REF_TABLES):
+        pytest.skip("the reference's whitening tables are only readable in the build container")
+    path = os.path.join(ROOT, "tests", "golden", "decode_golden.json")
+    got = {}
+    for sf, ldr, cr, s in golden_cases():
+        w = reference_whitening(sf, ldr)
+        assert w is not None and len(w) >= 279
+        a = bytes(g.decode(sf, cr, ldr, whitening_sequence=w).work(s))
+        assert a == codec.decode_pdu(sf, cr, ldr, w.tolist(), s.tolist())
+        got[f"sf{sf}_ldr{int(ldr)}_cr{cr}"] = {"n_symbols": len(s), "bytes_hex": a.hex(),
+                                                 "symbols_sha256": hashlib.sha256(s.tobytes()).hexdigest()}
+    if os.environ.get("LORA_WRITE_GOLDEN"):
+        json.dump(got, open(path, "w"), indent=1, sort_keys=True)
+    assert got == json.load(open(path))

@@ -114,3 +114,45 @@ def test_cfg4_long_capture_time_sharded(g):
     # every lattice phase was exercised by the random gaps
     locks = ref_tr["pos"][ref_tr["state"] == 4] if (ref_tr["state"] == 4).any() else ref_tr["pos"][:0]
     assert len(set((locks % (1 << sf)).tolist())) >= 4
+
+
+@pytest.mark.parametrize("ldr", [True, False])
+def test_cfg0_bytes_in_bytes_out(g, ldr):
+    """BASELINE configs[0] as the flowgraph runs it (examples/txrx_sim.grc:686-733): 64-byte PDUs -> encode -> mod ->
+    demod -> decode -> bytes.  encode and mod are the oracle's restatements (test infrastructure); demod is the GPU block,
+    decode the C ABI of include/lora_decode.h.  The chain on the GPU must give exactly the bytes the oracle's chain
+    (oracle demod -> restated decode) gives."""
+    from oracle import codec_oracle as codec
+    rng = np.random.default_rng(64 + ldr)
+    w = rng.integers(0, 64 if ldr else 256, 400).astype(np.uint16)
+    w[:8] &= 0x3F
+    payloads = [rng.integers(0, 256, 64).astype(np.uint8) for _ in range(3)]
+    frames, tx = [], []
+    for data in payloads:
+        s = np.array(codec.encode_pdu(8, 4, ldr, w.tolist(), data.tolist()), np.uint16)
+        if not ldr:
+            s[8:] &= 0xFF
+        tx.append(s)
+        frames.append(oracle.modulate(8, s, cases.SYNC_WORD))
+    frames.append(np.zeros(4 * 256, np.complex64))
+    cap = np.concatenate(frames)
+    blk = g.demod(8, ldr, cases.BETA, 2)
+    pdus = blk.work(cap)
+    blk.close()
+    ref_pdus = oracle.Demod(8, ldr, cases.BETA, 2).stream(cap)[0]
+    assert len(pdus) == len(ref_pdus) == 3
+    dec = g.decode(8, 4, ldr, False, whitening_sequence=w)
+    exact = 0
+    for p, r, data in zip(pdus, ref_pdus, payloads):
+        assert np.array_equal(p, r)                                           # same symbols as the oracle's block
+        out = bytes(dec.work(p))
+        assert out == codec.decode_pdu(8, 4, ldr, w.tolist(), [int(v) for v in r])
+        # 64 bytes are 128 nybbles: 6 go into the header block, the encoder's integer division keeps whole payload
+        # blocks only (encode_impl.cc:200) and drops the last 2 nybbles: 63 bytes come back
+        assert len(out) == 63
+        exact += out == bytes(data)[:63]
+    # Not asserted: exact > 0.  The reference's demod returns some payload symbols one bin low in a clean loopback
+    # (SURVEY 8a, "indicative behaviour"), which its Hamming code corrects only in part; the bar is the reference's
+    # output (the oracle chain above), not the transmitted bytes.  Without the modem the chain is exact at ldr True
+    # (tests/test_decode_chain.py).
+    print(f"cfg0 ldr={ldr}: {exact}/3 PDUs equal the transmitted bytes")
