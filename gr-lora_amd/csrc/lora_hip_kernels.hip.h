@@ -73,7 +73,41 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
 }
-__device__ __forceinline__ float magsq(float2 a) { return __builtin_fmaf(a.x, a.x, a.y * a.y); }
+// LORA_REF_ROUNDING 1: the two places where this kernel rounds differently from the reference's arithmetic follow it
+// instead (measured cost and effect: profiles/r02_ref_rounding.md):
+//   dechirp and window as VOLK's generic kernels do them -- (x*c) with four separately rounded products, one subtraction
+//   and one addition, then each component times the window tap (lib/demod_impl.cc:179/:183, :192) -- instead of one FMA
+//   complex multiply by the premultiplied tap;
+//   |X|^2 as demod_impl::argmax does under C++11 (std::pow(float, int) is double): (float)((double)re*re + (double)im*im)
+//   (:118, :125) instead of an f32 FMA.
+#ifndef LORA_REF_ROUNDING
+#define LORA_REF_ROUNDING 0
+#endif
+__device__ __forceinline__ float magsq(float2 a) {
+#if LORA_REF_ROUNDING
+  return (float)((double)a.x * (double)a.x + (double)a.y * (double)a.y);
+#else
+  return __builtin_fmaf(a.x, a.x, a.y * a.y);
+#endif
+}
+// dechirp (+ window): tap = chirp (x window premultiplied unless LORA_REF_ROUNDING), wk = window tap or 1
+__device__ __forceinline__ float2 dechirp(float2 x, float2 tap, float wk) {
+#if LORA_REF_ROUNDING
+  const float2 t = make_float2(x.x * tap.x - x.y * tap.y, x.x * tap.y + x.y * tap.x);
+  return make_float2(t.x * wk, t.y * wk);
+#else
+  (void)wk;
+  return make_float2(__builtin_fmaf(x.x, tap.x, -(x.y * tap.y)), __builtin_fmaf(x.x, tap.y, x.y * tap.x));
+#endif
+}
+__device__ __forceinline__ float2 make_tap(float2 chirp, float wk) {
+#if LORA_REF_ROUNDING
+  (void)wk;
+  return chirp;
+#else
+  return make_float2(chirp.x * wk, chirp.y * wk);
+#endif
+}
 // a * (-j)
 __device__ __forceinline__ float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }
 
@@ -288,12 +322,6 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #endif
 #ifndef LORA_SPREAD
 #define LORA_SPREAD 1     // SF12 sweep: the next window's IQ loads are spread over the last sub-transform as scalar-addressed buffer loads
-#endif
-#ifndef LORA_W4
-#define LORA_W4 0
-#endif
-#ifndef LORA_W4_KRES
-#define LORA_W4_KRES 8
 #endif
 #ifndef LORA_SF12_DIGITS
 #define LORA_SF12_DIGITS 1
@@ -736,14 +764,16 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
   // (taps = chirp x Kaiser window, multiplied once: see the dechirp below)
   float2 cc[CONST_OFF ? R : 1];
+  float cwin[(CONST_OFF && LORA_REF_ROUNDING) ? R : 1];
   if constexpr (CONST_OFF) {
     const float2 *__restrict__ chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
     const float *__restrict__ wsrc = p.win + tw;
 #pragma unroll
-    for (int k = 0; k < ((LORA_W4 && LOGN == 12 && !ANYF) ? LORA_W4_KRES : R); k++) {
+    for (int k = 0; k < R; k++) {
       const float2 ck = chirp[k * T];
       const float wk = (p.kind == 0) ? wsrc[k * T] : 1.0f;     // the SFD path has no window (:310)
-      cc[k] = make_float2(ck.x * wk, ck.y * wk);
+      cc[k] = make_tap(ck, wk);
+      if (LORA_REF_ROUNDING) cwin[k] = wk;
     }
   }
   // last pass with a table too big for LDS: the base twiddle W_M^((N/L)*(F*jm + rr)) of each of this
@@ -769,23 +799,6 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #pragma unroll
     for (int k = 0; k < R; k++) nx[k] = src[k * T];
   }
-  // LORA_W4 (SF12 steady-state sweep at four waves per SIMD, 128 registers): only the first KRES taps of a thread stay in
-  // registers; the chirp and window values of the others are fetched again (from L2) for every window, at the end of
-  // the previous one, when the transform's registers are free.  Same products, bit-identical results.
-  constexpr bool kW4 = LORA_W4 && CONST_OFF && LOGN == 12 && !ANYF;
-  constexpr int KRES = kW4 ? LORA_W4_KRES : R;
-  float2 cl_c[kW4 ? R - KRES : 1];
-  float cl_w[kW4 ? R - KRES : 1];
-  auto reload_taps = [&]() {
-    if constexpr (kW4) {
-      const float2 *chirp = (p.kind == 0 ? p.down : p.up) + p.off0 + tw;
-      const float *wsrc = p.win + tw;
-      asm volatile("" : "+v"(chirp), "+v"(wsrc));      // not loop-invariant as far as the compiler can tell
-#pragma unroll
-      for (int k = KRES; k < R; k++) { cl_c[k - KRES] = chirp[k * T]; cl_w[k - KRES] = wsrc[k * T]; }
-    }
-  };
-  reload_taps();
   // The store of window i is deferred into window i + 1 when the window spans several waves (the partials
   // meet behind the next window's barriers) and, measured, whenever F > 1; at F = 1 with a window inside one
   // wave storing at once frees the registers of the deferred state (SF7/SF8: +28 % / +41 %).
@@ -800,17 +813,10 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     LORA_STAMP(0);
     // ---- request this window's chirp/window taps, retire the previous window meanwhile -----
     float2 c[R];
-    if constexpr (kW4) {
+    float cw[LORA_REF_ROUNDING ? R : 1];
+    if constexpr (CONST_OFF) {
 #pragma unroll
-      for (int k = 0; k < KRES; k++) c[k] = cc[k];
-#pragma unroll
-      for (int k = KRES; k < R; k++) {
-        const float wk = (p.kind == 0) ? cl_w[k - KRES] : 1.0f;
-        c[k] = make_float2(cl_c[k - KRES].x * wk, cl_c[k - KRES].y * wk);
-      }
-    } else if constexpr (CONST_OFF) {
-#pragma unroll
-      for (int k = 0; k < R; k++) c[k] = cc[k];
+      for (int k = 0; k < R; k++) { c[k] = cc[k]; if (LORA_REF_ROUNDING) cw[k] = cwin[k]; }
     } else {
       const float2 *__restrict__ chirp = (cur.kind == 0 ? p.down : p.up) + cur.off + tw;
       const float *__restrict__ wsrc = p.win + tw;
@@ -821,7 +827,8 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #else
         const float2 ck = chirp[k * T];
         const float wk = (cur.kind == 0) ? wsrc[k * T] : 1.0f;   // the SFD path has no window (:310)
-        c[k] = make_float2(ck.x * wk, ck.y * wk);                // same products as the CONST_OFF taps: both paths agree bit for bit
+        c[k] = make_tap(ck, wk);                                  // same products as the CONST_OFF taps: both paths agree bit for bit
+        if (LORA_REF_ROUNDING) cw[k] = wk;
 #endif
       }
     }
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
       // (x*c)*w and FMA instead of VOLK's separately rounded products -- 4 VALU per sample instead of 8 and 16
       // fewer live registers; the FFT input differs from the reference's by at most ~1.5 ulp, three orders of
       // magnitude inside the 1e-4 bar (measured agreement with the oracle: profiles/r01_v13_accuracy.txt)
-      x[k] = cmul(nx[k], c[k]);
+      x[k] = dechirp(nx[k], c[k], cw[LORA_REF_ROUNDING ? k : 0]);
     }
     LORA_FENCE1();
     LORA_STAMP(1);    // operands landed + dechirp
@@ -957,7 +964,6 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
       LORA_STAMP(3);  // |X|^2 + per-thread argmax
       asm volatile("" ::: "memory");   // keep the next sub-transform's loads out of this one
     }
-    reload_taps();
     if constexpr (ANYF) {
       const float2 *__restrict__ src = p.iq + nxt.pos + tw;
 #pragma unroll

@@ -52,7 +52,8 @@ def main():
     factors = ANY_FACTORS if len(sys.argv) > 3 and sys.argv[3] == "any" else (1, 2, 2, 4)
     rng = np.random.default_rng(seed)
     t0, n_case, n_same, n_div, n_pdus, n_calls = time.time(), 0, 0, 0, 0, 0
-    while time.time() - t0 < budget:
+    max_cases = int(os.environ.get("LORA_FUZZ_CASES", "0"))       # > 0: stop after this many cases (same corpus for an A/B)
+    while time.time() - t0 < budget and (max_cases == 0 or n_case < max_cases):
         sf, f, ldr, cap, chunks = random_case(rng, factors)
         try:
             r = compare_with_oracle(g, sf, f, ldr, cap, chunks=chunks, name=f"case {n_case} sf{sf} f{f} ldr{ldr}")
