@@ -33,10 +33,7 @@ def my_range(n_items, rank, world_size):
     return partition(n_items, world_size)[rank]
 
 
-def demod_captures(capture_ids, load_capture, make_block):
-    """Demodulate the captures of this rank.  load_capture(id) -> complex64 array;
-    make_block() -> an object with work(samples) -> list of u16 arrays (gr-lora_amd.demod or any
-    stand-in with the same interface).  Returns {id: [pdu, ...]}."""
+def _demod_some(capture_ids, load_capture, make_block):
     out, blk = {}, None
     for cid in capture_ids:
         if blk is None:
@@ -51,6 +48,28 @@ def demod_captures(capture_ids, load_capture, make_block):
             blk = None
     if blk is not None and hasattr(blk, "close"):
         blk.close()
+    return out
+
+
+def demod_captures(capture_ids, load_capture, make_block, threads=1):
+    """Demodulate the captures of this rank.  load_capture(id) -> complex64 array;
+    make_block() -> an object with work(samples) -> list of u16 arrays (gr-lora_amd.demod or any
+    stand-in with the same interface).  Returns {id: [pdu, ...]}.
+
+    threads > 1: that many blocks (one handle and one HIP stream each) work through the captures side by side, as
+    the reference's flowgraph runs one demod block per channel on a scheduler thread of its own.  A short capture is
+    bound by the latency of its few launches and of its host-to-device copy, not by GPU time, so captures in flight
+    overlap those; the C ABI is re-entrant per handle and releases the interpreter lock while it works."""
+    ids = list(capture_ids)
+    if threads <= 1 or len(ids) <= 1:
+        return _demod_some(ids, load_capture, make_block)
+    from concurrent.futures import ThreadPoolExecutor
+    threads = min(threads, len(ids))
+    shares = [ids[t::threads] for t in range(threads)]
+    out = {}
+    with ThreadPoolExecutor(threads) as pool:
+        for part in pool.map(lambda share: _demod_some(share, load_capture, make_block), shares):
+            out.update(part)
     return out
 
 

@@ -18,21 +18,28 @@ shard = import_module("gr-lora_amd.shard")
 BETA, SYNC = 25.0, 0x12
 
 
-def cfg3(n_cap=1024, world=8, check_every=16):
+def cfg3(n_cap=1024, world=8, check_every=16, threads=1, pinned=False, caps_cache={}):
     sf, f, n = 10, 2, 1024
 
     def load(cid):
         syms = oracle.random_symbols(sf, 256, 4000 + cid)
         return np.concatenate([oracle.modulate(sf, syms, SYNC), np.zeros(4 * n, np.complex64)])
 
-    caps = [load(c) for c in range(n_cap)]                      # 2.2 GiB of host memory, generated up front
+    if "caps" not in caps_cache:
+        caps_cache["caps"] = [load(c) for c in range(n_cap)]   # 2.2 GiB of host memory, generated up front
+    caps = caps_cache["caps"]
+    if pinned:                                                  # the same samples in page-locked host memory (what a capture
+        if "pinned" not in caps_cache:                          # reader or an SDR driver that fills pinned buffers hands over)
+            import torch
+            caps_cache["pinned"] = [torch.from_numpy(c).pin_memory().numpy() for c in caps]
+        caps = caps_cache["pinned"]
     t0 = time.perf_counter()
     merged = {}
     for rank in range(world):
         lo, hi = shard.my_range(n_cap, rank, world)
         blk = g.demod(sf, False, BETA, f)                       # one block per rank, re-created per capture below
         blk.close()
-        merged.update(shard.demod_captures(range(lo, hi), lambda c: caps[c], lambda: g.demod(sf, False, BETA, f)))
+        merged.update(shard.demod_captures(range(lo, hi), lambda c: caps[c], lambda: g.demod(sf, False, BETA, f), threads=threads))
     dt = time.perf_counter() - t0
     out = shard.gather_pdus(merged, n_cap)
     n_sym = sum(len(p) for c in out for p in c)
@@ -41,10 +48,12 @@ def cfg3(n_cap=1024, world=8, check_every=16):
     for cid in range(0, n_cap, check_every):
         ref = d.stream(caps[cid])[0]
         bad += [p.tolist() for p in out[cid]] != [p.tolist() for p in ref]
-    print(f"configs[3]: {n_cap} captures x {len(caps[0])} samples (SF10 F2), 8 simulated ranks on one GPU: {dt:.2f} s "
+    print(f"configs[3]: {n_cap} captures x {len(caps[0])} samples (SF10 F2), 8 simulated ranks on one GPU, {threads} block(s) in flight per rank, {'pinned' if pinned else 'pageable'} host memory: {dt:.2f} s "
           f"({n_cap / dt:.0f} captures/s, {sum(len(c) for c in caps) * 8 / dt / 1e9:.2f} GB/s of IQ from host memory), "
           f"{sum(len(c) for c in out)} PDUs / {n_sym} symbols; {n_cap // check_every} captures checked against the oracle: "
           f"{bad} differ", flush=True)
+    return {"captures": n_cap, "pdus": sum(len(c) for c in out), "checked": n_cap // check_every, "differ": bad, "seconds": dt,
+            "gbs": sum(len(c) for c in caps) * 8 / dt / 1e9}
 
 
 def cfg4(seconds=3600.0, world=8):
@@ -95,11 +104,14 @@ def cfg4(seconds=3600.0, world=8):
     ndiff = sum(1 for a, b in zip(seq, ref) if a.tolist() != b.tolist()) + abs(len(seq) - len(ref))
     print(f"  oracle on one host core: {t_or:.1f} s, {len(ref)} PDUs; identical to the GPU block: {same_or}"
           + ("" if same_or else f" ({ndiff} PDUs differ)"), flush=True)
+    return {"packets": n_tx, "pdus": len(seq), "design_a_identical": same, "oracle_identical": same_or, "oracle_pdus_differ": ndiff,
+            "t_seq": t_seq, "t_sweep": t_sweep, "t_replay": t_rep, "t_oracle": t_or}
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["3", "4"]
     if "3" in which:
-        cfg3()
+        for th, pin in ((1, False), (1, False), (2, False), (4, False), (8, False), (1, True), (1, True), (2, True), (4, True), (8, True)):
+            cfg3(threads=th, pinned=pin)
     if "4" in which:
         cfg4()
