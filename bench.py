@@ -64,6 +64,21 @@ def cpu_baseline(capture, budget_s=12.0):
                    f"{calls} calls / {ffts} FFT windows / {pdus} PDUs per pass, {sec:.1f} s; "
                    f"value counts every FFT window, calls alone = {calls * reps / sec / 1e6:.6f} Msym/s"),
     }
+    # the same loop with the costs the reference pays for nothing taken out (SURVEY 8d "optimised CPU"): no per-call
+    # allocation, no dead multiply, F pruned N-point four-step transforms (vectorised) instead of one zero-padded
+    # M-point radix-2 transform, |X|^2 scan as a vector pass
+    try:
+        osec, ocalls, offts, opdus = oracle.time_stream(SF, False, BETA, FFT_FACTOR, capture, reps=1, optimised=True)
+        oreps = max(1, int(budget_s / 2 / max(osec, 1e-3)))
+        osec, ocalls, offts, opdus = oracle.time_stream(SF, False, BETA, FFT_FACTOR, capture, reps=oreps, optimised=True)
+        out["optimised"] = {
+            "value": round(offts * oreps / osec / 1e6, 6), "unit": "Msym/s", "cores": 1, "kind": "port",
+            "sample": (f"same capture x {oreps} passes through the same state machine with the window evaluation rewritten "
+                       f"(no allocation, no dead multiply, pruned four-step FFT, vector |X|^2 scan; own FFT, not FFTW/VOLK): "
+                       f"{ocalls} calls / {offts} FFT windows / {opdus} PDUs per pass, {osec:.1f} s"),
+        }
+    except Exception as e:
+        out["optimised"] = {"error": str(e)[:200]}
     # all cores of this box's share: separate processes that never touch the GPU
     ncores = max(1, min(16, os.cpu_count() or 1))
     try:

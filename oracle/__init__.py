@@ -58,6 +58,8 @@ def lib():
     L.lo_demod_stream.restype = sz
     L.lo_demod_time.argtypes = [u, i, f, u, vp, sz, u, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.lo_demod_time.restype = d
+    L.lo_demod_time_opt.argtypes = [u, i, f, u, vp, sz, u, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.lo_demod_time_opt.restype = d
     # chan_oracle.h
     L.lo_chan_design_taps.argtypes = [d, u, d, vp, sz]; L.lo_chan_design_taps.restype = sz
     L.lo_rotator.argtypes = [d, vp, vp, sz, vp, C.POINTER(u)]
@@ -182,12 +184,14 @@ class Demod:
         return pdus, (trace[:nc.value] if want_trace else None), nc.value, nf.value
 
 
-def time_stream(sf, ldr, beta, fft_factor, capture, reps=1):
-    """cpu_baseline leg: seconds for `reps` faithful passes; returns (sec, calls, ffts, pdus) per pass."""
+def time_stream(sf, ldr, beta, fft_factor, capture, reps=1, optimised=False):
+    """cpu_baseline leg: seconds for `reps` passes of the faithful loop (or of its optimised variant);
+    returns (sec, calls, ffts, pdus) per pass."""
     cap = np.ascontiguousarray(capture, np.complex64)
     nc, nf, npd = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-    sec = lib().lo_demod_time(sf, int(ldr), beta, fft_factor, _ptr(cap), len(cap), reps,
-                              C.byref(nc), C.byref(nf), C.byref(npd))
+    fn = lib().lo_demod_time_opt if optimised else lib().lo_demod_time
+    sec = fn(sf, int(ldr), beta, fft_factor, _ptr(cap), len(cap), reps,
+             C.byref(nc), C.byref(nf), C.byref(npd))
     return sec, nc.value, nf.value, npd.value
 
 

@@ -333,7 +333,11 @@ struct lo_demod {
   /* instrumentation */
   size_t n_ffts;
   unsigned last_n_sfd;
+  /* optimised CPU variant (lo_demod_time_opt): NULL = the faithful loop */
+  struct lo_fast *fast;
 };
+
+static void fast_destroy(struct lo_fast *q);
 
 static void state_reset_members(lo_demod *d)
 {
@@ -376,6 +380,7 @@ void lo_demod_destroy(lo_demod *d)
 {
   if (!d) return;
   fft_destroy(d->d_fft);
+  fast_destroy(d->fast);
   free(d->d_window); free(d->d_upchirp); free(d->d_downchirp); free(d->d_symbols);
   free(d->scratch); free(d);
 }
@@ -481,6 +486,170 @@ static void symbols_push(lo_demod *d, unsigned short s)
   d->d_symbols[d->n_symbols++] = s;
 }
 
+/* ---- optimised CPU variant of one window evaluation (cpu_baseline "optimised") -----------------------
+ * What a tuned CPU build of the reference's loop would do without changing what is computed: no per-call allocation,
+ * no dead multiply (:175), no memset/memcpy of the padded buffer; the zero-padded M = N*F point DFT as F pruned N-point
+ * transforms of x[n]*W_M^(r n) (bins F*k + r), each a radix-4 Stockham autosort FFT on split re/im arrays (contiguous inner
+ * loops that gcc vectorises) with per-stage twiddle tables; |X|^2 and the lowest-bin argmax fused into the last pass's
+ * output scan.  Same dechirp/window order as the faithful loop.  Results agree with it to rounding; it is a timing
+ * baseline, not the parity oracle. */
+typedef struct lo_fast {
+  unsigned n, f, n1, n2;             /* N = n1 * n2 (n1 <= n2, powers of two) */
+  float *ar, *ai, *br, *bi;          /* ping-pong work arrays, n each */
+  float *xr, *xi;                    /* dechirped (and windowed) input */
+  float *w1r, *w1i, *w2r, *w2i;      /* stage twiddles of the length-n1 and length-n2 column transforms */
+  float *mr, *mi;                    /* middle twiddles W_N^(k1*n2), n entries laid out [k1][n2] */
+  float *tr, *ti;                    /* input twist W_M^(r n), f*n entries */
+} lo_fast;
+
+static int fast_stage_table(unsigned len, float **wr, float **wi)
+{
+  size_t tw = 0;
+  for (unsigned l = len; l >= 4; l /= 4) tw += 3 * (l / 4);
+  if (posix_memalign((void **)wr, 64, sizeof(float) * (tw + 16)) || posix_memalign((void **)wi, 64, sizeof(float) * (tw + 16))) return -1;
+  size_t o = 0;
+  for (unsigned l = len; l >= 4; l /= 4)
+    for (unsigned k = 1; k <= 3; k++)
+      for (unsigned p = 0; p < l / 4; p++) {
+        const double a = -2.0 * M_PI * (double)(k * p) / (double)l;
+        (*wr)[o] = (float)cos(a); (*wi)[o] = (float)sin(a); o++;
+      }
+  return 0;
+}
+
+static lo_fast *fast_create(unsigned n, unsigned f)
+{
+  lo_fast *q = (lo_fast *)calloc(1, sizeof *q);
+  q->n = n; q->f = f;
+  unsigned logn = 0;
+  while ((1u << logn) < n) logn++;
+  q->n1 = 1u << (logn / 2); q->n2 = n / q->n1;
+  float **arr[] = { &q->ar, &q->ai, &q->br, &q->bi, &q->xr, &q->xi, &q->mr, &q->mi };
+  for (unsigned i = 0; i < 8; i++) if (posix_memalign((void **)arr[i], 64, sizeof(float) * n)) return NULL;
+  if (fast_stage_table(q->n1, &q->w1r, &q->w1i) || fast_stage_table(q->n2, &q->w2r, &q->w2i)) return NULL;
+  for (unsigned k1 = 0; k1 < q->n1; k1++)
+    for (unsigned c = 0; c < q->n2; c++) {
+      const double a = -2.0 * M_PI * (double)(k1 * c) / (double)n;
+      q->mr[k1 * q->n2 + c] = (float)cos(a); q->mi[k1 * q->n2 + c] = (float)sin(a);
+    }
+  if (posix_memalign((void **)&q->tr, 64, sizeof(float) * n * f) || posix_memalign((void **)&q->ti, 64, sizeof(float) * n * f)) return NULL;
+  for (unsigned r = 0; r < f; r++)
+    for (unsigned i = 0; i < n; i++) {
+      const double a = -2.0 * M_PI * (double)((unsigned long long)r * i % ((unsigned long long)n * f)) / (double)((unsigned long long)n * f);
+      q->tr[r * n + i] = (float)cos(a); q->ti[r * n + i] = (float)sin(a);
+    }
+  return q;
+}
+
+static void fast_destroy(struct lo_fast *q)
+{
+  if (!q) return;
+  free(q->ar); free(q->ai); free(q->br); free(q->bi); free(q->xr); free(q->xi); free(q->mr); free(q->mi);
+  free(q->w1r); free(q->w1i); free(q->w2r); free(q->w2i); free(q->tr); free(q->ti); free(q);
+}
+
+/* `len`-point forward Stockham transforms (decimation in frequency, radix 4 with a closing radix-2 pass) down the columns of a
+ * [len][v] array: element = a whole row of v contiguous values, so every inner loop is contiguous.  Input in (*xr, *xi), the
+ * other buffer in (*yr, *yi); on return (*xr, *xi) point at the result. */
+static void fast_col_fft(unsigned len, unsigned v, const float *wr, const float *wi, float **pxr, float **pxi, float **pyr, float **pyi)
+{
+  float *xr = *pxr, *xi = *pxi, *yr = *pyr, *yi = *pyi;
+  unsigned s = v;
+  size_t o = 0;
+  while (len >= 4) {
+    const unsigned n1 = len / 4;
+    const float *w1r = wr + o, *w1i = wi + o, *w2r = w1r + n1, *w2i = w1i + n1, *w3r = w2r + n1, *w3i = w2i + n1;
+    for (unsigned p = 0; p < n1; p++) {
+      const float c1 = w1r[p], s1 = w1i[p], c2 = w2r[p], s2 = w2i[p], c3 = w3r[p], s3 = w3i[p];
+      const float *restrict a_r = xr + s * p, *restrict a_i = xi + s * p, *restrict b_r = a_r + s * n1, *restrict b_i = a_i + s * n1;
+      const float *restrict c_r = b_r + s * n1, *restrict c_i = b_i + s * n1, *restrict d_r = c_r + s * n1, *restrict d_i = c_i + s * n1;
+      float *restrict o0r = yr + s * 4 * p, *restrict o0i = yi + s * 4 * p, *restrict o1r = o0r + s, *restrict o1i = o0i + s,
+            *restrict o2r = o1r + s, *restrict o2i = o1i + s, *restrict o3r = o2r + s, *restrict o3i = o2i + s;
+#pragma GCC ivdep
+      for (unsigned k = 0; k < s; k++) {
+        const float apc_r = a_r[k] + c_r[k], apc_i = a_i[k] + c_i[k], amc_r = a_r[k] - c_r[k], amc_i = a_i[k] - c_i[k];
+        const float bpd_r = b_r[k] + d_r[k], bpd_i = b_i[k] + d_i[k];
+        const float jb_r = -(b_i[k] - d_i[k]), jb_i = b_r[k] - d_r[k];           /* j*(b - d) */
+        o0r[k] = apc_r + bpd_r; o0i[k] = apc_i + bpd_i;
+        const float t1r = amc_r - jb_r, t1i = amc_i - jb_i;
+        o1r[k] = t1r * c1 - t1i * s1; o1i[k] = t1r * s1 + t1i * c1;
+        const float t2r = apc_r - bpd_r, t2i = apc_i - bpd_i;
+        o2r[k] = t2r * c2 - t2i * s2; o2i[k] = t2r * s2 + t2i * c2;
+        const float t3r = amc_r + jb_r, t3i = amc_i + jb_i;
+        o3r[k] = t3r * c3 - t3i * s3; o3i[k] = t3r * s3 + t3i * c3;
+      }
+    }
+    o += 3 * n1;
+    { float *t = xr; xr = yr; yr = t; t = xi; xi = yi; yi = t; }
+    len /= 4; s *= 4;
+  }
+  if (len == 2) {                              /* odd log2: one radix-2 pass closes the transform */
+#pragma GCC ivdep
+    for (unsigned k = 0; k < s; k++) {
+      yr[k] = xr[k] + xr[k + s]; yi[k] = xi[k] + xi[k + s];
+      yr[k + s] = xr[k] - xr[k + s]; yi[k + s] = xi[k] - xi[k + s];
+    }
+    { float *t = xr; xr = yr; yr = t; t = xi; xi = yi; yi = t; }
+  }
+  *pxr = xr; *pxi = xi; *pyr = yr; *pyi = yi;
+}
+
+/* forward N-point FFT of (ar, ai) by the four-step method: N = n1*n2, sample n = n2*r + c seen as row r, column c.
+ * n1-point transforms down the columns, times W_N^(k1*c), transpose, n2-point transforms down the columns again: the
+ * result X[k1 + n1*k2] lies at [k2][k1], i.e. in natural order.  Returns pointers to the result. */
+static void fast_fft(lo_fast *q, float **out_r, float **out_i)
+{
+  float *xr = q->ar, *xi = q->ai, *yr = q->br, *yi = q->bi;
+  const unsigned n1 = q->n1, n2 = q->n2;
+  fast_col_fft(n1, n2, q->w1r, q->w1i, &xr, &xi, &yr, &yi);                   /* x: [k1][c] */
+  for (unsigned i = 0; i < q->n; i++) {                                       /* middle twiddles */
+    const float re = xr[i] * q->mr[i] - xi[i] * q->mi[i], im = xr[i] * q->mi[i] + xi[i] * q->mr[i];
+    xr[i] = re; xi[i] = im;
+  }
+  for (unsigned r0 = 0; r0 < n1; r0 += 8)                                      /* transpose into y: [c][k1], 8x8 blocks */
+    for (unsigned c0 = 0; c0 < n2; c0 += 8)
+      for (unsigned r = r0; r < r0 + 8 && r < n1; r++)
+        for (unsigned c = c0; c < c0 + 8 && c < n2; c++) { yr[c * n1 + r] = xr[r * n2 + c]; yi[c * n1 + r] = xi[r * n2 + c]; }
+  fast_col_fft(n2, n1, q->w2r, q->w2i, &yr, &yi, &xr, &xi);                   /* y: [k2][k1] */
+  *out_r = yr; *out_i = yi;
+}
+
+/* one window: in[0..N) x chirp[0..N) (x window), zero-padded M-point spectrum, lowest-bin argmax of |X|^2 */
+static unsigned short fast_eval(lo_demod *d, const lo_c32 *in, const lo_c32 *chirp, int windowed, float *max_out)
+{
+  lo_fast *q = d->fast;
+  const unsigned n = q->n, f = q->f;
+  for (unsigned i = 0; i < n; i++) {          /* VOLK generic order: (x*c) then *w */
+    float re = in[i].re * chirp[i].re - in[i].im * chirp[i].im;
+    float im = in[i].re * chirp[i].im + in[i].im * chirp[i].re;
+    if (windowed) { re *= d->d_window[i]; im *= d->d_window[i]; }
+    q->xr[i] = re; q->xi[i] = im;
+  }
+  float best = -1.0f; unsigned best_idx = 0;
+  for (unsigned r = 0; r < f; r++) {
+    if (r == 0) { memcpy(q->ar, q->xr, sizeof(float) * n); memcpy(q->ai, q->xi, sizeof(float) * n); }
+    else {
+      const float *tr = q->tr + (size_t)r * n, *ti = q->ti + (size_t)r * n;
+      for (unsigned i = 0; i < n; i++) { q->ar[i] = q->xr[i] * tr[i] - q->xi[i] * ti[i]; q->ai[i] = q->xr[i] * ti[i] + q->xi[i] * tr[i]; }
+    }
+    float *yr, *yi;
+    fast_fft(q, &yr, &yi);
+    float *restrict pw = yr == q->ar ? q->br : q->ar;                          /* the work array the result is not in */
+    float m = -1.0f; unsigned mi = 0;
+#pragma GCC ivdep
+    for (unsigned k = 0; k < n; k++)            /* |X|^2 through double as the reference's argmax does */
+      pw[k] = (float)((double)yr[k] * (double)yr[k] + (double)yi[k] * (double)yi[k]);
+    for (unsigned k = 0; k < n; k++) m = pw[k] > m ? pw[k] : m;
+    while (mi < n && pw[mi] != m) mi++;
+    if (mi == n) mi = 0;                        /* all NaN: the reference's scan keeps index 0 */
+    const unsigned bin = f * mi + r;
+    if (m > best || (m == best && bin < best_idx)) { best = m; best_idx = bin; }
+  }
+  d->n_ffts++;
+  if (max_out) *max_out = best;
+  return (unsigned short)best_idx;
+}
+
 /* PDU sink used by general_work's S_OUT case */
 typedef struct {
   uint16_t *sym_out; size_t max_syms, n_syms;
@@ -497,14 +666,24 @@ static unsigned short general_work(lo_demod *d, const lo_c32 *in, lo_sink *sink,
   const size_t bytes = d->d_fft_size * sizeof(lo_c32);
   /* :165-167 three per-call allocations (volk_malloc -> posix_memalign) */
   lo_c32 *buffer = NULL, *up_block = NULL, *down_block = NULL;
-  if (posix_memalign((void **)&buffer, 64, bytes)) buffer = NULL;
-  if (posix_memalign((void **)&up_block, 64, bytes)) up_block = NULL;
-  if (posix_memalign((void **)&down_block, 64, bytes)) down_block = NULL;
+  const int fast = d->fast != NULL;             /* optimised CPU variant: no allocations, no dead multiply, pruned transform */
+  if (!fast) {
+    if (posix_memalign((void **)&buffer, 64, bytes)) buffer = NULL;
+    if (posix_memalign((void **)&up_block, 64, bytes)) up_block = NULL;
+    if (posix_memalign((void **)&down_block, 64, bytes)) down_block = NULL;
+  }
 
   const int st_in = d->d_state;
   unsigned short off_used = 0;
   d->last_n_sfd = 0;
 
+  float up_val;
+  if (fast) {
+    if (d->d_state == LO_S_READ_HEADER || d->d_state == LO_S_READ_PAYLOAD) off_used = d->d_offset;
+    max_index = fast_eval(d, in, &d->d_downchirp[off_used], 1, &up_val);
+    d->d_power = up_val;                                                      /* argmax(..., update_squelch = true), :133-137 */
+    d->d_squelched = (d->d_power > d->d_threshold) ? 0 : 1;
+  } else {
   /* :175 dead multiply (result only used by DUMP_IQ / overwritten in the SFD loop) */
   volk_32fc_x2_multiply_32fc(down_block, in, &d->d_upchirp[0], d->d_num_symbols);
 
@@ -517,8 +696,8 @@ static unsigned short general_work(lo_demod *d, const lo_c32 *in, lo_sink *sink,
   volk_32fc_32f_multiply_32fc(up_block, up_block, &d->d_window[0], d->d_num_symbols); /* :192 */
 
   padded_fft(d, up_block);                                                    /* :201-203 */
-  float up_val;
   max_index = argmax(d, d->d_fft->out, 1, &up_val);                           /* :206 */
+  }
   const unsigned short up_idx = max_index;
   hist_push_front(d->d_argmax_history, &d->n_argmax_history, max_index);      /* :207 */
   if (d->n_argmax_history > REQUIRED_PREAMBLE_CHIRPS) d->n_argmax_history--;  /* :209-212 */
@@ -555,10 +734,14 @@ static unsigned short general_work(lo_demod *d, const lo_c32 *in, lo_sink *sink,
     }
     for (int ol = 0; ol < d->d_overlaps; ol++) {
       d->d_offset = (unsigned short)(((ol * d->d_num_symbols) / d->d_overlaps) % d->d_num_symbols);
-      for (int j = 0; j < d->d_num_symbols; j++) buffer[j] = in[d->d_offset + j];
-      volk_32fc_x2_multiply_32fc(down_block, buffer, &d->d_upchirp[d->d_offset], d->d_num_symbols);
-      padded_fft(d, down_block);
-      max_index = argmax(d, d->d_fft->out, 0, NULL);
+      if (fast) {
+        max_index = fast_eval(d, in + d->d_offset, &d->d_upchirp[d->d_offset], 0, NULL);
+      } else {
+        for (int j = 0; j < d->d_num_symbols; j++) buffer[j] = in[d->d_offset + j];
+        volk_32fc_x2_multiply_32fc(down_block, buffer, &d->d_upchirp[d->d_offset], d->d_num_symbols);
+        padded_fft(d, down_block);
+        max_index = argmax(d, d->d_fft->out, 0, NULL);
+      }
       d->last_n_sfd++;
       hist_push_front(d->d_sfd_history, &d->n_sfd_history, max_index);
       if (d->n_sfd_history > REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR) {
@@ -615,7 +798,7 @@ static unsigned short general_work(lo_demod *d, const lo_c32 *in, lo_sink *sink,
     tr->consumed = num_consumed; tr->val = up_val; tr->n_sfd = d->last_n_sfd;
   }
 
-  free(down_block); free(up_block); free(buffer);                             /* :445-447 */
+  if (!fast) { free(down_block); free(up_block); free(buffer); }              /* :445-447 */
   return num_consumed;                                                        /* :443 */
 }
 
@@ -653,12 +836,16 @@ size_t lo_demod_stream(lo_demod *d, const lo_c32 *capture, size_t n,
   return np;
 }
 
-double lo_demod_time(unsigned sf, int ldr, float beta, unsigned fft_factor,
-                     const lo_c32 *capture, size_t n, unsigned reps,
-                     size_t *n_calls, size_t *n_ffts, size_t *n_pdus)
+static double demod_time(int optimised, unsigned sf, int ldr, float beta, unsigned fft_factor,
+                         const lo_c32 *capture, size_t n, unsigned reps,
+                         size_t *n_calls, size_t *n_ffts, size_t *n_pdus)
 {
   lo_demod *d = lo_demod_create(sf, ldr, beta, fft_factor);
   if (!d) return -1.0;
+  if (optimised) {
+    d->fast = fast_create(d->d_num_symbols, d->d_fft_size_factor);
+    if (!d->fast) { lo_demod_destroy(d); return -1.0; }
+  }
   const size_t max_syms = 1 << 20, max_pdus = 1 << 16;
   uint16_t *syms = (uint16_t *)malloc(sizeof(uint16_t) * max_syms);
   uint32_t *plen = (uint32_t *)malloc(sizeof(uint32_t) * max_pdus);
@@ -678,4 +865,17 @@ double lo_demod_time(unsigned sf, int ldr, float beta, unsigned fft_factor,
   free(syms); free(plen);
   lo_demod_destroy(d);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+double lo_demod_time(unsigned sf, int ldr, float beta, unsigned fft_factor, const lo_c32 *capture, size_t n, unsigned reps,
+                     size_t *n_calls, size_t *n_ffts, size_t *n_pdus)
+{
+  return demod_time(0, sf, ldr, beta, fft_factor, capture, n, reps, n_calls, n_ffts, n_pdus);
+}
+
+/* the same loop with the optimised window evaluation (fast_eval); power-of-two N*F only */
+double lo_demod_time_opt(unsigned sf, int ldr, float beta, unsigned fft_factor, const lo_c32 *capture, size_t n, unsigned reps,
+                         size_t *n_calls, size_t *n_ffts, size_t *n_pdus)
+{
+  return demod_time(1, sf, ldr, beta, fft_factor, capture, n, reps, n_calls, n_ffts, n_pdus);
 }

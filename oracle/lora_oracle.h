@@ -111,6 +111,11 @@ size_t lo_demod_stream(lo_demod *d, const lo_c32 *capture, size_t n,
 double lo_demod_time(unsigned sf, int ldr, float beta, unsigned fft_factor,
                      const lo_c32 *capture, size_t n, unsigned reps,
                      size_t *n_calls, size_t *n_ffts, size_t *n_pdus);
+/* the same loop with an optimised window evaluation (no per-call allocation, no dead multiply, pruned radix-4 Stockham
+ * transform, fused argmax): the "optimised CPU" baseline of SURVEY 8d; results agree with the faithful loop to rounding */
+double lo_demod_time_opt(unsigned sf, int ldr, float beta, unsigned fft_factor,
+                         const lo_c32 *capture, size_t n, unsigned reps,
+                         size_t *n_calls, size_t *n_ffts, size_t *n_pdus);
 
 #ifdef __cplusplus
 }

@@ -142,3 +142,15 @@ def test_f1_premature_lock_is_reproduced():
     outcome at F=1 hinges on a flat-spectrum window and is recorded in the golden traces."""
     g = load_golden("clean_sf8_f1_ldr0")
     assert int(g["pdu_len"].size) == 1     # the first frame is lost, the second decodes
+
+
+@pytest.mark.parametrize("sf,factor", [(7, 1), (8, 2), (9, 4), (10, 2), (11, 2)])
+def test_optimised_cpu_variant_walks_the_same_stream(sf, factor):
+    """bench.py's cpu_baseline["optimised"] leg (same state machine, rewritten window evaluation: no allocation, no dead
+    multiply, pruned four-step FFT) must do the same work as the faithful loop: same calls, FFT windows and PDUs."""
+    from importlib import import_module
+    synth = import_module("gr-lora_amd.synth")
+    cap = synth.capture(sf, 200_000, symbols_per_packet=24, seed=11)
+    a = oracle.time_stream(sf, False, 25.0, factor, cap, reps=1)
+    b = oracle.time_stream(sf, False, 25.0, factor, cap, reps=1, optimised=True)
+    assert a[1:] == b[1:] and a[3] > 0
