@@ -18,18 +18,24 @@ IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED = 1, 2, 4, 8, 16
 
 WIN_DESC_DTYPE = np.dtype([("pos", "<u8"), ("chirp_off", "<u2"), ("kind", "u1"), ("reserved", "u1", (5,))])
 assert WIN_DESC_DTYPE.itemsize == 16
+# lora_win_run, include/lora_hip_demod.h
+WIN_RUN_DTYPE = np.dtype([("pos0", "<u8"), ("stride", "<u4"), ("count", "<u4"), ("chirp_off", "<u2"),
+                          ("chirp_off_step", "<u2"), ("kind", "u1"), ("reserved", "u1", (3,))])
+assert WIN_RUN_DTYPE.itemsize == 24
 
 # every symbol include/lora_hip_demod.h declares
 EXPORTS = (
     "lora_hip_strerror", "lora_hip_last_hip_error", "lora_hip_make_chirp_tables", "lora_hip_make_kaiser",
     "lora_hip_demod_create", "lora_hip_demod_destroy", "lora_hip_demod_set_stream", "lora_hip_demod_batch",
-    "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
+    "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_batch_runs",
+    "lora_hip_host_alloc", "lora_hip_host_free", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
     "lora_hip_demod_kernel_name", "lora_hip_demod_stage_iq", "lora_hip_demod_stage_iq2",
     "lora_hip_demod_stage_iq2_dev", "lora_hip_demod_fetch", "lora_demod_core_work_device", "lora_demod_core_set_stream",
     # include/lora_demod_core.h
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
-    "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset",
+    "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset", "lora_demod_core_set_plan", "lora_demod_core_set_collect", "lora_demod_core_collected",
+    "lora_demod_core_plans", "lora_demod_core_replans", "lora_demod_core_on_demand", "lora_demod_core_rollbacks",
     # include/lora_hip_chan.h
     "lora_hip_chan_design_taps", "lora_hip_chan_create", "lora_hip_chan_destroy", "lora_hip_chan_set_stream",
     "lora_hip_chan_last_hip_error", "lora_hip_chan_reset", "lora_hip_chan_output_count", "lora_hip_chan_work",
@@ -95,7 +101,14 @@ def lib():
     L.lora_demod_core_destroy.argtypes = [vp]; L.lora_demod_core_destroy.restype = None
     L.lora_demod_core_work.argtypes = [vp, vp, sz, PDU_CB, vp]; L.lora_demod_core_work.restype = i
     L.lora_demod_core_set_trace.argtypes = [vp, vp, sz]; L.lora_demod_core_set_trace.restype = i
-    for nme in ("lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches"):
+    L.lora_demod_core_set_plan.argtypes = [vp, i]; L.lora_demod_core_set_plan.restype = i
+    L.lora_demod_core_set_collect.argtypes = [vp, i]; L.lora_demod_core_set_collect.restype = i
+    L.lora_demod_core_collected.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.lora_demod_core_collected.restype = i
+    L.lora_hip_demod_batch_runs.argtypes = [vp, vp, sz, vp, sz, vp, vp, u]; L.lora_hip_demod_batch_runs.restype = i
+    L.lora_hip_host_alloc.argtypes = [C.POINTER(vp), sz]; L.lora_hip_host_alloc.restype = i
+    L.lora_hip_host_free.argtypes = [vp]; L.lora_hip_host_free.restype = None
+    for nme in ("lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches",
+                "lora_demod_core_plans", "lora_demod_core_replans", "lora_demod_core_on_demand", "lora_demod_core_rollbacks"):
         getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = u64
     L.lora_demod_core_state.argtypes = [vp]; L.lora_demod_core_state.restype = i
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
@@ -232,6 +245,25 @@ class HipDemod:
             n_samples //= 2
         self._check(lib().lora_hip_demod_batch_strided(self._h, pi, n_samples, pos0, stride, count, chirp_off,
                                                        chirp_off_step, kind, po, pv, flags))
+        return out_idx, out_val
+
+    def batch_runs(self, iq, runs, out_idx=None, out_val=None):
+        """lora_hip_demod_batch_runs: runs = [(pos0, stride, count, chirp_off, chirp_off_step, kind), ...] evaluated in one
+        launch, results back to back in run order."""
+        r = np.zeros(len(runs), WIN_RUN_DTYPE)
+        for k, u in enumerate(runs):
+            r["pos0"][k], r["stride"][k], r["count"][k], r["chirp_off"][k], r["chirp_off_step"][k], r["kind"][k] = u
+        count = int(r["count"].sum())
+        out_idx, out_val = self._outputs(count, out_idx, out_val)
+        pi, di = _ptr(iq); po, do = _ptr(out_idx); pv, dv = _ptr(out_val)
+        assert do == dv
+        flags = (IQ_ON_DEVICE if di else 0) | (OUT_ON_DEVICE if do else 0)
+        if iq is None:
+            flags |= IQ_STAGED
+            n_samples = self._staged_n
+        else:
+            n_samples = iq.numel() if _is_torch(iq) else len(iq)
+        self._check(lib().lora_hip_demod_batch_runs(self._h, pi, n_samples, r.ctypes.data, len(r), po, pv, flags))
         return out_idx, out_val
 
     def batch_strided_noalloc(self, iq, pos0, stride, count, out_idx, out_val, chirp_off=0, chirp_off_step=0,

@@ -13,6 +13,7 @@
 // Product code: never calls anything under oracle/.
 #include "lora_demod_core.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,22 +52,104 @@ struct Run {
   }
 };
 
+// one planned sweep: its results lie at [at, at + count) of the plan's page-locked result arrays
+struct PRun {
+  uint64_t start = 0; uint32_t stride = 1, count = 0;      // stride: N or N/16, a power of two
+  unsigned off0 = 0, off_step = 0;
+  size_t at = 0;
+  bool find(uint64_t pos, unsigned off, unsigned n, size_t *k, size_t *rem = nullptr) const {
+    if (pos < start) return false;
+    const uint64_t d = pos - start;
+    if (d & (stride - 1)) return false;
+    const uint64_t q = d >> __builtin_ctz(stride);
+    if (q >= count) return false;
+    if (((off0 + q * off_step) & (n - 1)) != off) return false;
+    *k = at + (size_t)q;
+    if (rem) *rem = count - (size_t)q;        // windows of this sweep from k on
+    return true;
+  }
+};
+
+// page-locked host array that only grows
+template <typename T>
+struct Pin {
+  T *p = nullptr; size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return LORA_HIP_OK;
+    lora_hip_host_free(p); p = nullptr; cap = 0;
+    const size_t nc = n + n / 4 + 1024;
+    void *q = nullptr;
+    const int rc = lora_hip_host_alloc(&q, nc * sizeof(T));
+    if (rc) return rc;
+    p = static_cast<T *>(q); cap = nc;
+    return LORA_HIP_OK;
+  }
+  Pin() = default;
+  Pin(const Pin &) = delete;
+  Pin &operator=(const Pin &) = delete;
+  ~Pin() { lora_hip_host_free(p); }
+};
+
+// What one work() call (or one stretch of a very long one) evaluates ahead of the state machine, in a fixed number of
+// launches whatever the number of packets:
+//   A    every up-path window with chirp offset 0 on the N/16 lattice, all 16 phases (the read index never leaves that
+//        lattice: num_consumed is N or ol*N/16 + 5N/4, :314), one strided sweep;
+//   SFD  behind every lattice position at which the preamble rule (:247-273) holds, on its phase, the at most
+//        9*16 + 1 overlapped windows one sync attempt can evaluate (:283-292), all of them in one launch;
+//   READ the header/payload windows of the chain of packets a dry run of the state machine (same code, squelch taken
+//        from A: a chirp offset only rotates the spectrum) predicts, one launch.
+// The state machine then runs over these results; whatever the plan did not foresee is evaluated on demand as before
+// and the READ plan is redone from that point.  Results are exact either way: a plan only decides WHICH windows are
+// evaluated early, never what a window's result is.
+struct Plan {
+  bool active = false;
+  uint64_t a_start = 0; size_t a_count = 0;          // window j of A starts at a_start + j*N/16
+  Pin<uint16_t> a_idx; Pin<float> a_val;
+  std::vector<PRun> sfd[OVERLAP_FACTOR]; size_t sfd_cur[OVERLAP_FACTOR] = {0};
+  Pin<uint16_t> s_idx;
+  std::vector<PRun> rd; size_t rd_cur = 0;
+  Pin<uint16_t> r_idx; Pin<float> r_val;
+  unsigned replans = 0;
+};
+
+// a header/payload call the first pass answered from a prediction: where its exact result goes once it is known
+struct Patch { uint64_t pos; uint32_t row, flat; uint16_t off, pre; uint8_t div4, sq; };
+// the read index, call count and PDU count at a call that enters S_RESET: everything else is cleared by that call (:215-229)
+struct Snap { uint64_t pos, calls; size_t pdus; };
+
 }  // namespace
 
-struct lora_demod_core {
-  // configuration (demod_impl.h:44-49)
-  unsigned d_sf = 0; bool d_ldr = false; float d_beta = 0; unsigned d_fft_size_factor = 0;
-  unsigned d_num_symbols = 0, d_fft_size = 0;
-  lora_hip_demod_t *hip = nullptr;
-  // reference state (demod_impl.h:43-70)
+// the reference's std::vector histories (newest first, :207-212, :318-320) as fixed arrays: they never hold more than
+// REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR + 1 entries
+template <unsigned CAP>
+struct Hist {
+  unsigned short v[CAP + 1]; unsigned n = 0;
+  size_t size() const { return n; }
+  void clear() { n = 0; }
+  void push_front(unsigned short x) { memmove(v + 1, v, n * sizeof(unsigned short)); v[0] = x; n++; }
+  void pop_back() { n--; }
+  unsigned short operator[](size_t i) const { return v[i]; }
+};
+
+// everything general_work reads and writes between calls (demod_impl.h:43-70) plus the read index: a dry run saves and
+// restores exactly this
+struct WalkState {
   int d_state = LORA_S_RESET;
   unsigned d_overlaps = OVERLAP_DEFAULT, d_offset = 0;
   float d_power = .000000001f, d_threshold = 0.005f;      // :87-88
   bool d_squelched = false;
   unsigned d_preamble_idx = 0, d_sfd_idx = 0;
-  std::vector<unsigned short> d_argmax_history, d_sfd_history;
+  Hist<REQUIRED_PREAMBLE_CHIRPS> d_argmax_history; Hist<REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR> d_sfd_history;
   unsigned d_sync_recovery_counter = 0;
   std::vector<unsigned short> d_symbols;
+  uint64_t pos = 0;
+};
+
+struct lora_demod_core : WalkState {
+  // configuration (demod_impl.h:44-49)
+  unsigned d_sf = 0; bool d_ldr = false; float d_beta = 0; unsigned d_fft_size_factor = 0;
+  unsigned d_num_symbols = 0, d_fft_size = 0;
+  lora_hip_demod_t *hip = nullptr;
   // stream framing: the samples [base, base + total()) of the framed stream are buf (carried over from
   // earlier calls) followed, during a work() call, by that call's input, which is never copied on the
   // host: only the GPU reads samples, the host keeps what a later call may still need; pos = read index
@@ -77,7 +160,23 @@ struct lora_demod_core {
   // from cur_in where it lies
   bool cur_dev = false; size_t head_n = 0;
   size_t total() const { return buf.size() + cur_n; }
-  uint64_t base = 0, pos = 0;
+  uint64_t base = 0;
+  // planned evaluation (Plan above): mode 0 off, 1 when the input is long enough to pay for it, 2 always
+  Plan plan; int plan_mode = 1;
+  bool shadow = false;           // dry run: no launches, no PDUs, misses are predicted and recorded in `needs`
+  std::vector<PRun> needs;
+  std::vector<uint16_t> fire;
+  // first pass of a plan (plan_walk): the dry run keeps its trace rows and PDUs, to be completed from the READ stage
+  bool deferred = false, pred = false;
+  std::vector<Patch> patches; std::vector<Snap> snaps;
+  std::vector<uint16_t> pdu_syms; std::vector<size_t> pdu_off;
+  bool collect = false;                                        // lora_demod_core_set_collect
+  std::vector<uint16_t> col_syms; std::vector<uint64_t> col_off;
+  long fault_at = -1; uint64_t n_pred = 0, n_rollbacks = 0;    // LORA_CORE_FAULT: test hook, mispredict that window
+  uint64_t n_plans = 0, n_replans = 0, n_demand = 0;
+  // LORA_CORE_TIMING=1: seconds per stage of the last work() call on stderr (lattice sweep, SFD scan, SFD launch, dry
+  // run, READ launch, state machine)
+  bool timing = false; double t_stage[6] = {0, 0, 0, 0, 0, 0}, t_cb = 0;
   // GPU result caches
   std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
   size_t last_up = 0;            // index of the sweep that answered the last up-path lookup
@@ -118,17 +217,16 @@ int ensure_staged(lora_demod_core *c) {
   return LORA_HIP_OK;
 }
 
-int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size_t count, unsigned off0,
-               unsigned off_step, unsigned kind) {
+// one strided sweep into caller-given result arrays (val may be NULL with LORA_HIP_NO_VAL in xflags)
+int launch_strided(lora_demod_core *c, uint64_t start, uint64_t stride, size_t count, unsigned off0, unsigned off_step,
+                   unsigned kind, uint16_t *idx, float *val, unsigned xflags) {
   int rc = ensure_staged(c);
   if (rc) return rc;
-  r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
-  r.idx.assign(count, 0); r.val.assign(count, 0.f);
   const uint64_t s0 = start - c->base;
   if (!c->cur_dev || c->head_n == c->cur_n) {
     // everything the windows touch is in the staging buffer
     rc = lora_hip_demod_batch_strided(c->hip, nullptr, c->total(), s0, stride, count, off0, off_step,
-                                      kind, r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+                                      kind, idx, val, LORA_HIP_IQ_STAGED | xflags);
     c->n_launches++;
   } else {
     // device-resident input: the windows that start inside the carry come from the staged head, all others
@@ -142,20 +240,372 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
     rc = LORA_HIP_OK;
     if (k0) {
       rc = lora_hip_demod_batch_strided(c->hip, nullptr, carry + c->head_n, s0, stride, k0, off0, off_step, kind,
-                                        r.idx.data(), r.val.data(), LORA_HIP_IQ_STAGED);
+                                        idx, val, LORA_HIP_IQ_STAGED | xflags);
       c->n_launches++;
     }
     if (!rc && count > k0) {
       const unsigned n = c->d_num_symbols;
       const unsigned off_k0 = (unsigned)((off0 + (uint64_t)k0 * off_step) & (n - 1));
       rc = lora_hip_demod_batch_strided(c->hip, c->cur_in, c->cur_n, s0 + (uint64_t)k0 * stride - carry, stride,
-                                        count - k0, off_k0, off_step, kind, r.idx.data() + k0, r.val.data() + k0,
-                                        LORA_HIP_IQ_ON_DEVICE);
+                                        count - k0, off_k0, off_step, kind, idx + k0, val ? val + k0 : nullptr,
+                                        LORA_HIP_IQ_ON_DEVICE | xflags);
       c->n_launches++;
     }
   }
-  if (rc) { r.idx.clear(); r.val.clear(); return fail(c, rc, "batch_strided"); }
+  if (rc) return fail(c, rc, "batch_strided");
   c->n_windows += count;
+  return LORA_HIP_OK;
+}
+
+int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size_t count, unsigned off0,
+               unsigned off_step, unsigned kind) {
+  r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
+  r.idx.assign(count, 0); r.val.assign(count, 0.f);
+  const int rc = launch_strided(c, start, stride, count, off0, off_step, kind, r.idx.data(), r.val.data(), 0);
+  if (rc) { r.idx.clear(); r.val.clear(); }
+  return rc;
+}
+
+// ---- planned evaluation (struct Plan) ----------------------------------------------------------------------------
+// one finished PDU (:420-422): to the callback, and into the block's own list when collecting
+inline void deliver(lora_demod_core *c, lora_pdu_cb cb, void *user, const uint16_t *syms, size_t n) {
+  if (c->collect) {
+    c->col_syms.insert(c->col_syms.end(), syms, syms + n);
+    c->col_off.push_back(c->col_syms.size());
+  }
+  if (cb) cb(user, syms, n);
+}
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+constexpr int kShadowStop = 1;                    // dry run met something it cannot predict: stop it there
+constexpr size_t kPlanMinSymbols = 128;           // plan_mode 1: shorter inputs are evaluated on demand
+constexpr size_t kPlanChunk = (size_t)1 << 22;    // lattice positions per plan (a longer input is planned in stretches)
+constexpr size_t kPlanMaxSfd = (size_t)1 << 23;   // SFD windows per plan
+constexpr unsigned kMaxReplans = 16;
+constexpr unsigned kSfdSpan = 9 * OVERLAP_FACTOR + 1;   // :283-292: nine full calls, then the call that gives up evaluates one
+
+inline bool split_input(const lora_demod_core *c) { return c->cur_dev && c->head_n != c->cur_n; }
+
+// append a planned sweep; with a device-resident input it is cut where its windows stop starting inside the carry
+void push_planned(lora_demod_core *c, std::vector<PRun> &list, PRun r) {
+  if (split_input(c)) {
+    const uint64_t carry = c->buf.size(), s0 = r.start - c->base;
+    if (s0 < carry) {
+      const uint64_t k = (carry - s0 + r.stride - 1) / r.stride;
+      if (k < r.count) {
+        PRun a = r; a.count = (uint32_t)k;
+        list.push_back(a);
+        r.start += k * r.stride; r.count -= (uint32_t)k;
+        r.off0 = (unsigned)((r.off0 + k * r.off_step) & (c->d_num_symbols - 1));
+      }
+    }
+  }
+  list.push_back(r);
+}
+
+// all sweeps of `runs` in one launch (two with a device-resident input when some windows start inside the carry)
+int launch_planned(lora_demod_core *c, std::vector<PRun *> &runs, unsigned kind, Pin<uint16_t> &idx, Pin<float> *val) {
+  if (runs.empty()) return LORA_HIP_OK;
+  int rc = ensure_staged(c);
+  if (rc) return rc;
+  const bool split = split_input(c);
+  const uint64_t carry = c->buf.size();
+  std::vector<lora_win_run> early, late;
+  size_t n_early = 0, n_late = 0;
+  auto mk = [&](const PRun &r, uint64_t pos0) {
+    lora_win_run u; memset(&u, 0, sizeof u);
+    u.pos0 = pos0; u.stride = r.stride; u.count = r.count; u.chirp_off = (uint16_t)r.off0; u.chirp_off_step = (uint16_t)r.off_step;
+    u.kind = (uint8_t)kind;
+    return u;
+  };
+  for (PRun *r : runs) {
+    const uint64_t s0 = r->start - c->base;
+    if (!split || s0 < carry) { r->at = n_early; n_early += r->count; early.push_back(mk(*r, s0)); }
+  }
+  if (split)
+    for (PRun *r : runs) {
+      const uint64_t s0 = r->start - c->base;
+      if (s0 >= carry) { r->at = n_early + n_late; n_late += r->count; late.push_back(mk(*r, s0 - carry)); }
+    }
+  const size_t total = n_early + n_late;
+  if ((rc = idx.ensure(total))) return fail(c, rc, "host_alloc");
+  if (val && (rc = val->ensure(total))) return fail(c, rc, "host_alloc");
+  const unsigned flags = LORA_HIP_OUT_PINNED | (val ? 0u : (unsigned)LORA_HIP_NO_VAL);
+  if (n_early) {
+    rc = lora_hip_demod_batch_runs(c->hip, nullptr, split ? carry + c->head_n : c->total(), early.data(), early.size(),
+                                   idx.p, val ? val->p : nullptr, flags | LORA_HIP_IQ_STAGED);
+    c->n_launches += 2;
+    if (rc) return fail(c, rc, "batch_runs");
+  }
+  if (n_late) {
+    rc = lora_hip_demod_batch_runs(c->hip, c->cur_in, c->cur_n, late.data(), late.size(), idx.p + n_early,
+                                   val ? val->p + n_early : nullptr, flags | LORA_HIP_IQ_ON_DEVICE);
+    c->n_launches += 2;
+    if (rc) return fail(c, rc, "batch_runs");
+  }
+  c->n_windows += total;
+  return LORA_HIP_OK;
+}
+
+inline bool plan_a_find(const Plan &P, uint64_t pos, unsigned step, size_t *k) {
+  if (pos < P.a_start) return false;
+  const uint64_t d = pos - P.a_start;
+  if (d & (step - 1)) return false;
+  const uint64_t q = d >> __builtin_ctz(step);
+  if (q >= P.a_count) return false;
+  *k = (size_t)q;
+  return true;
+}
+
+// sorted sweeps, read indices only grow: a cursor finds the sweep
+inline bool planned_find(const std::vector<PRun> &L, size_t &cur, uint64_t pos, unsigned off, unsigned n, size_t *k,
+                         size_t *rem = nullptr) {
+  if (L.empty()) return false;
+  if (cur >= L.size()) cur = L.size() - 1;
+  while (cur + 1 < L.size() && L[cur + 1].start <= pos) cur++;
+  for (size_t b = 0; b < 3 && b <= cur; b++)
+    if (L[cur - b].find(pos, off, n, k, rem)) return true;
+  return false;
+}
+
+int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consumed);
+
+// SFD stage: behind every lattice position of A at which the preamble rule holds (:247-273: the newest four windows of
+// one phase within +-1 of the newest, not squelched), the windows one sync attempt entered there can evaluate
+int plan_sfd(lora_demod_core *c) {
+  Plan &P = c->plan;
+  const double t0 = now_s();
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  const uint16_t *ai = P.a_idx.p; const float *av = P.a_val.p;
+  const uint64_t end = c->base + c->total();
+  const uint64_t lat0 = P.a_start / step;
+  const uint64_t jmax = (end - n - P.a_start) / step;      // last lattice index at which a window still fits
+  const float thr = c->d_threshold;
+  size_t total = 0;
+  const size_t lag = OVERLAP_FACTOR;
+  // the rule for every lattice position at once (straight-line code the compiler vectorises), then the few hits
+  static_assert(LORA_PREAMBLE_TOLERANCE == 1, "the wrap-around compare below is written for a tolerance of 1");
+  c->fire.resize(P.a_count + 8);
+  uint16_t *fire = c->fire.data();
+  memset(fire, 0, (P.a_count < 3 * lag ? P.a_count : 3 * lag) * sizeof(uint16_t));
+  memset(fire + P.a_count, 0, 8 * sizeof(uint16_t));
+  for (size_t j = 3 * lag; j < P.a_count; j++) {        // 16-bit lanes only: eight positions per SSE2 operation
+    const unsigned short i0 = ai[j];
+    // |a - b| <= 1  <=>  (u16)(a - b + 1) <= 2 for bins below 65535
+    fire[j] = (uint16_t)(((unsigned short)(i0 - ai[j - lag] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 2 * lag] + 1) <= 2) &
+                         ((unsigned short)(i0 - ai[j - 3 * lag] + 1) <= 2));
+  }
+  for (size_t j = 3 * lag; j < P.a_count && total < kPlanMaxSfd; j++) {
+    if (!fire[j]) {
+      uint64_t w;
+      while (j + 4 < P.a_count && (memcpy(&w, fire + j, 8), w == 0)) j += 4;
+      if (!fire[j]) continue;
+    }
+    if (!(av[j] > thr)) continue;                       // squelched (:268): no sync attempt
+    const uint64_t lo = j + lag;                           // the sync attempt's first call is the next one on this phase
+    uint64_t hi = lo + kSfdSpan;
+    if (hi > jmax + 1) hi = jmax + 1;
+    if (lo >= hi) continue;
+    const unsigned ph = (unsigned)((lat0 + j) % OVERLAP_FACTOR);
+    std::vector<PRun> &L = P.sfd[ph];
+    if (!L.empty()) {
+      PRun &b = L.back();
+      const uint64_t blo = (b.start - P.a_start) / step;
+      if (lo <= blo + b.count) {                           // overlaps or touches the last sweep of this phase
+        if (hi > blo + b.count) { total += (size_t)(hi - blo - b.count); b.count = (uint32_t)(hi - blo); }
+        continue;
+      }
+    }
+    PRun r;
+    r.start = P.a_start + lo * step; r.stride = step; r.count = (uint32_t)(hi - lo);
+    r.off0 = (unsigned)(((r.start % n) + n - ph * step) % n); r.off_step = step;
+    L.push_back(r);
+    total += r.count;
+  }
+  std::vector<PRun *> all;
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) {
+    if (split_input(c)) {                                  // cut the sweeps that straddle the end of the carry
+      std::vector<PRun> cut;
+      for (const PRun &r : P.sfd[ph]) push_planned(c, cut, r);
+      P.sfd[ph].swap(cut);
+    }
+    for (PRun &r : P.sfd[ph]) all.push_back(&r);
+    P.sfd_cur[ph] = 0;
+  }
+  const double t1 = now_s();
+  const int rc = launch_planned(c, all, LORA_WIN_SFD, P.s_idx, nullptr);
+  c->t_stage[1] += t1 - t0; c->t_stage[2] += now_s() - t1;
+  return rc;
+}
+
+// READ stage: a dry run of the state machine from its present state over what is known (A, the SFD sweeps, every
+// cached result); the header/payload windows it asks for are recorded and then evaluated in one launch
+int plan_reads(lora_demod_core *c) {
+  Plan &P = c->plan;
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  P.rd.clear(); P.rd_cur = 0; c->needs.clear();
+  const double t0 = now_s();
+  const WalkState saved = *c;
+  const uint64_t saved_calls = c->n_calls;
+  size_t saved_cur[OVERLAP_FACTOR];
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) saved_cur[ph] = P.sfd_cur[ph];
+  const size_t saved_last_up = c->last_up;
+  c->shadow = true;
+  const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
+  const uint64_t a_last = P.a_start + (uint64_t)(P.a_count - 1) * step;
+  int rc = LORA_HIP_OK;
+  try {
+    while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
+      unsigned consumed = 0;
+      rc = general_work(c, nullptr, nullptr, &consumed);
+      if (rc) break;
+      c->pos += consumed;
+    }
+  } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
+  c->shadow = false;
+  static_cast<WalkState &>(*c) = saved;
+  c->n_calls = saved_calls; c->last_up = saved_last_up;
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd_cur[ph] = saved_cur[ph];
+  if (rc != LORA_HIP_OK && rc != kShadowStop) return rc;
+  // two windows more per packet: the squelch of the real windows may fall a symbol later than predicted
+  const uint64_t end = c->base + c->total();
+  for (PRun &r : c->needs) {
+    for (int extra = 0; extra < 2; extra++)
+      if (r.start + (uint64_t)(r.count + 1) * r.stride <= end - (need - n)) r.count++;
+    push_planned(c, P.rd, r);
+  }
+  c->needs.clear();
+  std::vector<PRun *> all;
+  for (PRun &r : P.rd) all.push_back(&r);
+  const double t1 = now_s();
+  const int rl = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val);
+  c->t_stage[3] += t1 - t0; c->t_stage[4] += now_s() - t1;
+  return rl;
+}
+
+// First pass of a plan: the state machine runs ONCE over what is known, as in plan_reads, but keeps what it produces --
+// trace rows, PDUs -- with the header/payload calls answered from predictions (the squelch from A, the bin unknown).
+// After the READ stage has evaluated those windows, every predicted squelch decision is checked against the exact
+// maximum; if all hold, the path the first pass took IS the reference's path, and the bins are filled in: symbols
+// (:363-413 arithmetic) and trace rows.  The state machine is then put back at the last call that entered S_RESET
+// (which clears all state, :215-229) and runs for real from there, so that its final state never rests on a prediction.
+// A decision that does not hold puts it back at the S_RESET call before that packet instead.
+int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
+  Plan &P = c->plan;
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR, F = c->d_fft_size_factor;
+  P.rd.clear(); P.rd_cur = 0; c->needs.clear();
+  c->patches.clear(); c->snaps.clear(); c->pdu_syms.clear(); c->pdu_off.clear();
+  const double t0 = now_s();
+  const WalkState saved = *c;
+  const uint64_t saved_calls = c->n_calls;
+  c->shadow = true; c->deferred = true;
+  const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
+  const uint64_t a_last = P.a_start + (uint64_t)(P.a_count - 1) * step;
+  int rc = LORA_HIP_OK;
+  try {
+    while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
+      unsigned consumed = 0;
+      rc = general_work(c, nullptr, nullptr, &consumed);
+      if (rc) break;
+      c->pos += consumed;
+    }
+  } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
+  c->shadow = false; c->deferred = false;
+  auto to_start = [&]() { static_cast<WalkState &>(*c) = saved; c->n_calls = saved_calls; };
+  if (rc != LORA_HIP_OK && rc != kShadowStop) { to_start(); return rc; }
+  const uint64_t end = c->base + c->total();
+  for (PRun &r : c->needs) {
+    for (int extra = 0; extra < 2; extra++)
+      if (r.start + (uint64_t)(r.count + 1) * r.stride <= end - (need - n)) r.count++;
+    push_planned(c, P.rd, r);
+  }
+  c->needs.clear();
+  std::vector<PRun *> all;
+  for (PRun &r : P.rd) all.push_back(&r);
+  const double t1 = now_s();
+  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val);
+  const double t2 = now_s();
+  c->t_stage[3] += t1 - t0; c->t_stage[4] += t2 - t1;
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd_cur[ph] = 0;     // the read index goes back
+  P.rd_cur = 0;
+  if (rc) { to_start(); return rc; }
+  // where the real run resumes: the last S_RESET call, or one before the first prediction that did not hold
+  bool from_start = c->snaps.empty();
+  Snap rb = from_start ? Snap{0, saved_calls, 0} : c->snaps.back();
+  size_t cur = 0, k = 0;
+  for (const Patch &pt : c->patches) {
+    if (pt.row >= rb.calls) break;
+    const bool found = planned_find(P.rd, cur, pt.pos, pt.off, n, &k);
+    if (found && (!(P.r_val.p[k] > c->d_threshold)) == (pt.sq != 0)) continue;
+    c->n_rollbacks++;
+    from_start = true; rb = Snap{0, saved_calls, 0};
+    for (size_t s = c->snaps.size(); s-- > 0;)
+      if (c->snaps[s].calls <= pt.row) { rb = c->snaps[s]; from_start = false; break; }
+    break;
+  }
+  cur = 0;
+  for (const Patch &pt : c->patches) {
+    if (pt.row >= rb.calls) break;
+    if (!planned_find(P.rd, cur, pt.pos, pt.off, n, &k)) break;            // (checked above)
+    const unsigned idx = P.r_idx.p[k];
+    const unsigned sym = (n + idx / F - pt.pre / F) % n;                   // :373, :398-401
+    c->pdu_syms[pt.flat] = (unsigned short)(pt.div4 ? sym / 4 : sym);
+    if (c->trace && pt.row < c->max_trace) { c->trace[pt.row].idx = (uint16_t)idx; c->trace[pt.row].val = P.r_val.p[k]; }
+  }
+  const double t3 = now_s();
+  for (size_t i = 0; i < rb.pdus; i++) {
+    const size_t b = c->pdu_off[i], e = i + 1 < c->pdu_off.size() ? c->pdu_off[i + 1] : c->pdu_syms.size();
+    deliver(c, cb, user, c->pdu_syms.data() + b, e - b);
+  }
+  if (from_start) to_start();
+  else { c->d_state = LORA_S_RESET; c->pos = rb.pos; c->n_calls = rb.calls; }
+  P.rd_cur = 0;
+  c->t_stage[3] += t3 - t2; c->t_cb += now_s() - t3;
+  return LORA_HIP_OK;
+}
+
+// Start a plan at the read index (see struct Plan).  Leaves the plan inactive when the input is too short to pay.
+int plan_begin(lora_demod_core *c, lora_pdu_cb cb, void *user) {
+  Plan &P = c->plan;
+  P.active = false; P.replans = 0;
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) { P.sfd[ph].clear(); P.sfd_cur[ph] = 0; }
+  P.rd.clear(); P.rd_cur = 0;
+  if (c->plan_mode == 0) return LORA_HIP_OK;
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  const uint64_t end = c->base + c->total();
+  const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
+  if (end < c->pos + need) return LORA_HIP_OK;
+  size_t count = (size_t)((end - c->pos - n) / step + 1);
+  if (c->plan_mode == 1 && count < kPlanMinSymbols * OVERLAP_FACTOR) return LORA_HIP_OK;
+  if (count > kPlanChunk) count = kPlanChunk;
+  int rc;
+  if ((rc = P.a_idx.ensure(count)) || (rc = P.a_val.ensure(count))) return fail(c, rc, "host_alloc");
+  // results handed in through lora_demod_core_preload (time sharding: other GPUs swept the lattice) are used as they are
+  bool have = false;
+  if (!c->pre_runs.empty()) {
+    memset(P.a_idx.p, 0xFF, count * sizeof(uint16_t));     // 0xFFFF is no bin: N*F < 65536
+    for (const Run &r : c->pre_runs) {
+      if (r.stride != n || r.off0 != 0 || r.off_step != 0 || r.kind != LORA_WIN_UP || (r.start % step)) continue;
+      size_t k = 0;
+      if (r.start < c->pos) k = (size_t)((c->pos - r.start + n - 1) / n);
+      for (; k < r.idx.size(); k++) {
+        const uint64_t p = r.start + (uint64_t)k * n;
+        if ((p - c->pos) % step) break;
+        const uint64_t j = (p - c->pos) / step;
+        if (j >= count) break;
+        P.a_idx.p[j] = r.idx[k]; P.a_val.p[j] = r.val[k];
+      }
+    }
+    have = true;
+    for (size_t j = 0; j < count; j++) if (P.a_idx.p[j] == 0xFFFF) { have = false; break; }
+  }
+  const double t0 = now_s();
+  if (!have && (rc = launch_strided(c, c->pos, step, count, 0, 0, LORA_WIN_UP, P.a_idx.p, P.a_val.p, LORA_HIP_OUT_PINNED))) return rc;
+  c->t_stage[0] += now_s() - t0;
+  P.a_start = c->pos; P.a_count = count; P.active = true;
+  c->n_plans++;
+  if ((rc = plan_sfd(c))) { P.active = false; return rc; }
+  if ((rc = plan_walk(c, cb, user))) { P.active = false; return rc; }
   return LORA_HIP_OK;
 }
 
@@ -163,6 +613,11 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
 int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, float *val) {
   const unsigned n = c->d_num_symbols;
   size_t k;
+  Plan &P = c->plan;
+  if (P.active) {
+    if (off == 0 && plan_a_find(P, pos, n / OVERLAP_FACTOR, &k)) { *idx = P.a_idx.p[k]; *val = P.a_val.p[k]; return LORA_HIP_OK; }
+    if (planned_find(P.rd, P.rd_cur, pos, off, n, &k)) { *idx = P.r_idx.p[k]; *val = P.r_val.p[k]; return LORA_HIP_OK; }
+  }
   // consecutive calls walk along one sweep: try the one that answered last before searching them all
   if (c->last_up < c->up_runs.size() && c->up_runs[c->last_up].find(pos, off, n, &k)) {
     *idx = c->up_runs[c->last_up].idx[k]; *val = c->up_runs[c->last_up].val[k];
@@ -174,6 +629,27 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
   for (size_t r = c->pre_runs.size(); r-- > 0;) {
     if (c->pre_runs[r].find(pos, off, n, &k)) { *idx = c->pre_runs[r].idx[k]; *val = c->pre_runs[r].val[k]; return LORA_HIP_OK; }
   }
+  if (c->shadow) {
+    // dry run: the window is asked for, not evaluated.  Its maximum is that of the offset-0 window at the same place
+    // (a chirp offset only rotates the spectrum), which is all the state machine's path depends on while reading.
+    if (!P.active || !plan_a_find(P, pos, n / OVERLAP_FACTOR, &k)) return kShadowStop;
+    *idx = P.a_idx.p[k]; *val = P.a_val.p[k];
+    c->pred = true;
+    if (c->deferred && c->fault_at >= 0 && (long)c->n_pred++ == c->fault_at) *val = 0.f;
+    if (!c->needs.empty() && c->needs.back().off0 == off &&
+        c->needs.back().start + (uint64_t)c->needs.back().count * n == pos) c->needs.back().count++;
+    else { PRun r; r.start = pos; r.stride = n; r.count = 1; r.off0 = off; r.off_step = 0; c->needs.push_back(r); }
+    return LORA_HIP_OK;
+  }
+  if (P.active && P.replans < kMaxReplans) {
+    // the plan did not foresee this window (an SFD search it had no sweep for, a squelch that fell elsewhere): redo
+    // its READ stage from here
+    P.replans++; c->n_replans++;
+    const int rp = plan_reads(c);
+    if (rp) return rp;
+    if (planned_find(P.rd, P.rd_cur, pos, off, n, &k)) { *idx = P.r_idx.p[k]; *val = P.r_val.p[k]; return LORA_HIP_OK; }
+  }
+  c->n_demand++;
   // miss: drop batches that lie entirely behind the read index
   auto behind = [&](const Run &u) { return u.start + (uint64_t)u.idx.size() * u.stride <= c->pos; };
   for (size_t r = 0; r < c->up_runs.size();) {
@@ -212,12 +688,24 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
 // traffic (a packet every ~85 symbol times): 458 -> 92 launches per 386 packets; sparse traffic (the 1-hour
 // capture of BASELINE configs[4], a packet per second): gaps are too long, every attempt keeps its own sweep of at
 // most 10 calls x 16 windows (:283-292), as before.
-int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx) {
+int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx, const uint16_t **seq, size_t *seq_n) {
   const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
   size_t k;
+  if (c->plan.active) {
+    const unsigned ph = (unsigned)((call_pos & (n - 1)) / step);
+    size_t rem = 0;
+    if (planned_find(c->plan.sfd[ph], c->plan.sfd_cur[ph], call_pos + off, off, n, &k, &rem)) {
+      *idx = c->plan.s_idx.p[k];
+      // the windows of one call lie N/16 apart with offsets N/16 apart: the same sweep holds the next ones in order
+      if (seq) { *seq = c->plan.s_idx.p + k; *seq_n = rem; }
+      return LORA_HIP_OK;
+    }
+  }
   for (size_t r = c->sfd_runs.size(); r-- > 0;) {
     if (c->sfd_runs[r].find(call_pos + off, off, n, &k)) { *idx = c->sfd_runs[r].idx[k]; return LORA_HIP_OK; }
   }
+  if (c->shadow) return kShadowStop;
+  c->n_demand++;
   // miss: drop sweeps that lie entirely behind the read index
   for (size_t r = 0; r < c->sfd_runs.size();) {
     const Run &u = c->sfd_runs[r];
@@ -254,20 +742,24 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
   unsigned num_consumed = N;
   unsigned short max_index = 0;
   bool preamble_found = false, sfd_found = false;
+  const uint16_t *seq = nullptr; size_t seq_n = 0;      // planned results of this call's SFD windows, when one sweep holds them
   const int st_in = c->d_state;
   unsigned n_sfd = 0;
 
   // :177-206 up path; chirp offset is d_offset only while reading header/payload
   const unsigned off = (c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) ? c->d_offset : 0;
   float max_val = 0.f;
+  if (c->deferred && c->d_state == LORA_S_RESET) c->snaps.push_back(Snap{c->pos, c->n_calls, c->pdu_off.size()});
+  c->pred = false;
   int rc = get_up(c, c->pos, off, &max_index, &max_val);
   if (rc) return rc;
+  const bool pred = c->pred;
   const unsigned short up_idx = max_index;
   // argmax(..., update_squelch = true), :133-137
   c->d_power = max_val;
   c->d_squelched = (c->d_power > c->d_threshold) ? false : true;
   // :207-212
-  c->d_argmax_history.insert(c->d_argmax_history.begin(), max_index);
+  c->d_argmax_history.push_front(max_index);
   if (c->d_argmax_history.size() > REQUIRED_PREAMBLE_CHIRPS) c->d_argmax_history.pop_back();
 
   switch (c->d_state) {
@@ -301,15 +793,19 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       }
       for (int ol = 0; ol < (int)c->d_overlaps; ol++) {
         c->d_offset = ((ol * N) / c->d_overlaps) % N;
-        if ((rc = get_sfd(c, c->pos, c->d_offset, &max_index))) return rc;
+        if ((size_t)ol < seq_n) max_index = seq[ol];
+        else if ((rc = get_sfd(c, c->pos, c->d_offset, &max_index, ol == 0 ? &seq : nullptr, &seq_n))) return rc;
         n_sfd++;
-        c->d_sfd_history.insert(c->d_sfd_history.begin(), max_index);
+        c->d_sfd_history.push_front(max_index);
         if (c->d_sfd_history.size() > REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR) {
           c->d_sfd_history.pop_back();
-          sfd_found = true;
           c->d_sfd_idx = c->d_sfd_history[0];
-          for (int i = 1; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++)
-            if (abs(int(c->d_sfd_idx) - int(c->d_sfd_history[i])) > int(F) * LORA_SFD_TOLERANCE) sfd_found = false;
+          int worst = 0;                                           // same test as the reference's loop, without branches
+          for (int i = 1; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++) {
+            const int dv = abs(int(c->d_sfd_idx) - int(c->d_sfd_history.v[i]));
+            worst = dv > worst ? dv : worst;
+          }
+          sfd_found = !(worst > int(F) * LORA_SFD_TOLERANCE);
           if (sfd_found) {
             num_consumed = (ol * N) / c->d_overlaps + 5 * N / 4;   // skip last quarter chirp
             c->d_offset = (c->d_offset + (N / 4)) % N;
@@ -325,6 +821,9 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       if (c->d_squelched) c->d_state = LORA_S_OUT;
       else if (c->d_symbols.size() == 7) c->d_state = LORA_S_READ_PAYLOAD;
       c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
+      if (c->deferred && pred)
+        c->patches.push_back(Patch{c->pos, (uint32_t)c->n_calls, (uint32_t)(c->pdu_syms.size() + c->d_symbols.size() - 1),
+                                   (uint16_t)off, (uint16_t)c->d_preamble_idx, 1, (uint8_t)c->d_squelched});
       break;
 
     case LORA_S_READ_PAYLOAD:                                       // :391-413
@@ -333,10 +832,16 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
         c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
       else
         c->d_symbols.push_back((unsigned short)((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N));
+      if (c->deferred && pred)
+        c->patches.push_back(Patch{c->pos, (uint32_t)c->n_calls, (uint32_t)(c->pdu_syms.size() + c->d_symbols.size() - 1),
+                                   (uint16_t)off, (uint16_t)c->d_preamble_idx, (uint8_t)(c->d_ldr ? 1 : 0), (uint8_t)c->d_squelched});
       break;
 
     case LORA_S_OUT:                                                // :418-431
-      if (cb) cb(user, c->d_symbols.data(), c->d_symbols.size());
+      if (c->deferred) {
+        c->pdu_off.push_back(c->pdu_syms.size());
+        c->pdu_syms.insert(c->pdu_syms.end(), c->d_symbols.begin(), c->d_symbols.end());
+      } else if (!c->shadow) deliver(c, cb, user, c->d_symbols.data(), c->d_symbols.size());
       c->d_state = LORA_S_RESET;
       break;
 
@@ -344,6 +849,7 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       break;
   }
 
+  if (c->shadow && !c->deferred) { *consumed = num_consumed & 0xFFFFu; return LORA_HIP_OK; }
   if (c->trace && c->n_calls < c->max_trace) {
     lora_core_trace &t = c->trace[c->n_calls];
     t.pos = c->pos; t.state = (uint16_t)st_in; t.chirp_off = (uint16_t)off; t.idx = up_idx;
@@ -365,6 +871,9 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   if (!c) return LORA_HIP_ENOMEM;
   int rc = lora_hip_demod_create(&c->hip, device, sf, fft_factor, beta, nullptr, nullptr, nullptr);
   if (rc) { delete c; return rc; }
+  if (const char *e = getenv("LORA_CORE_FAULT")) c->fault_at = atol(e);
+  if (const char *e = getenv("LORA_CORE_TIMING")) c->timing = atoi(e) != 0;
+  if (const char *e = getenv("LORA_CORE_PLAN")) { const int m = atoi(e); if (m >= 0 && m <= 2) c->plan_mode = m; }
   c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor;
   c->d_num_symbols = 1u << sf;                                      // :79
   c->d_fft_size = c->d_fft_size_factor * c->d_num_symbols;          // :80
@@ -391,6 +900,9 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   for (uint64_t &m : c->sfd_last_miss) m = 0;
   c->staged = false;
   c->n_calls = 0; c->n_windows = 0; c->n_launches = 0;
+  c->n_plans = 0; c->n_replans = 0; c->n_demand = 0;
+  c->plan.active = false; c->shadow = false; c->deferred = false;
+  c->n_pred = 0; c->n_rollbacks = 0;
   c->err.clear();
   return LORA_HIP_OK;
 }
@@ -422,11 +934,29 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   if (n_in) c->staged = false;
   const uint64_t need = (uint64_t)c->d_num_symbols + (uint64_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1;
   int rc = LORA_HIP_OK;
-  while (c->base + c->total() >= c->pos + need) {
+  c->col_syms.clear(); c->col_off.assign(1, 0);
+  for (double &t : c->t_stage) t = 0;
+  c->t_cb = 0;
+  const double t_begin = now_s();
+  try { rc = plan_begin(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
+  const double t_walk = now_s();
+  while (!rc && c->base + c->total() >= c->pos + need) {
+    if (c->plan.active && c->pos > c->plan.a_start + (uint64_t)(c->plan.a_count - 1) * (c->d_num_symbols / OVERLAP_FACTOR)) {
+      try { rc = plan_begin(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }   // next stretch of a long input
+      if (rc) break;
+    }
     unsigned consumed = 0;
     rc = general_work(c, cb, user, &consumed);
     if (rc) break;
     c->pos += consumed;                                             // consume_each, :443
+  }
+  if (c->timing) {
+    const double t_end = now_s();
+    c->t_stage[5] = t_end - t_walk - (c->t_stage[0] + c->t_stage[1] + c->t_stage[2] + c->t_stage[3] + c->t_stage[4] - (t_walk - t_begin));
+    fprintf(stderr, "[core] work %zu samples: lattice sweep %.3f ms | SFD scan %.3f | SFD launch %.3f | dry run %.3f | READ launch %.3f | "
+                    "state machine %.3f | PDU callbacks of the first pass %.3f | total %.3f ms; %llu launches so far\n", n_in, c->t_stage[0] * 1e3, c->t_stage[1] * 1e3,
+            c->t_stage[2] * 1e3, c->t_stage[3] * 1e3, c->t_stage[4] * 1e3, (c->t_stage[5] - c->t_cb) * 1e3, c->t_cb * 1e3, (t_end - t_begin) * 1e3,
+            (unsigned long long)c->n_launches);
   }
   // keep what can still be read, [pos, end), as the next call's carry; cached runs keep absolute positions
   try {
@@ -458,6 +988,7 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   c->base = c->pos > c->base ? c->pos : c->base;
   c->cur_in = nullptr; c->cur_n = 0; c->cur_dev = false; c->head_n = 0;
   c->staged = false;
+  c->plan.active = false;           // planned results describe this call's samples
   if (rc) return rc;
   return LORA_HIP_OK;
 }
@@ -474,6 +1005,29 @@ int lora_demod_core_preload(lora_demod_core_t *c, uint64_t start, size_t count, 
   } catch (const std::bad_alloc &) { return LORA_HIP_ENOMEM; }
   return LORA_HIP_OK;
 }
+
+int lora_demod_core_set_collect(lora_demod_core_t *c, int on) {
+  if (!c) return LORA_HIP_EINVAL;
+  c->collect = on != 0;
+  c->col_syms.clear(); c->col_off.assign(1, 0);
+  return LORA_HIP_OK;
+}
+int lora_demod_core_collected(const lora_demod_core_t *c, const uint16_t **symbols, const uint64_t **offsets, size_t *n_pdus) {
+  if (!c || !symbols || !offsets || !n_pdus) return LORA_HIP_EINVAL;
+  *symbols = c->col_syms.data(); *offsets = c->col_off.data();
+  *n_pdus = c->col_off.empty() ? 0 : c->col_off.size() - 1;
+  return LORA_HIP_OK;
+}
+
+int lora_demod_core_set_plan(lora_demod_core_t *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return LORA_HIP_EINVAL;
+  c->plan_mode = mode;
+  return LORA_HIP_OK;
+}
+uint64_t lora_demod_core_plans(const lora_demod_core_t *c) { return c ? c->n_plans : 0; }
+uint64_t lora_demod_core_replans(const lora_demod_core_t *c) { return c ? c->n_replans : 0; }
+uint64_t lora_demod_core_on_demand(const lora_demod_core_t *c) { return c ? c->n_demand : 0; }
+uint64_t lora_demod_core_rollbacks(const lora_demod_core_t *c) { return c ? c->n_rollbacks : 0; }
 
 int lora_demod_core_set_trace(lora_demod_core_t *c, lora_core_trace *rows, size_t max_rows) {
   if (!c) return LORA_HIP_EINVAL;

@@ -35,6 +35,7 @@ struct lora_hip_demod {
   // staging for host-resident arguments (grown on demand, reused)
   float2 *d_iq = nullptr; size_t cap_iq = 0, staged_n = 0;
   void *d_desc = nullptr; size_t cap_desc = 0;
+  unsigned char *d_runs = nullptr; size_t cap_runs = 0;   // lora_hip_demod_batch_runs: the run list in HBM
   // results for host callers: one device block [n_win floats | n_win u16] and its pinned mirror, so that
   // a call costs one device-to-host copy
   unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
@@ -114,6 +115,26 @@ Variant make_variant_anyf(const char *name) {
             lora_hip::min_waves(LOGN, 1) * 4 / (lora_hip::block_threads(LOGN, 1) / 64), name, 0, 0, 0, name};
   v.lds_const = v.lds; v.wpb_const = v.wpb; v.blocks_per_cu_const = v.blocks_per_cu;
   return v;
+}
+
+// one thread per window: find its run by bisection over the runs' first-window numbers, write its descriptor
+struct RunDev { unsigned long long pos0; unsigned stride, first; unsigned short off, off_step; unsigned kind; };
+__global__ void expand_runs_kernel(const RunDev *runs, unsigned n_runs, unsigned n_win, unsigned nmask, lora_hip::WinDesc *desc) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_win) return;
+  unsigned lo = 0, hi = n_runs - 1;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi + 1) >> 1;
+    if (runs[mid].first <= i) lo = mid; else hi = mid - 1;
+  }
+  const RunDev r = runs[lo];
+  const unsigned k = i - r.first;
+  lora_hip::WinDesc d;
+  d.pos = r.pos0 + (unsigned long long)k * r.stride;
+  d.off = (unsigned short)((r.off + k * r.off_step) & nmask);
+  d.kind = (unsigned char)r.kind;
+  for (int b = 0; b < 5; b++) d.pad[b] = 0;
+  desc[i] = d;
 }
 
 #define LORA_VARIANTS_SF(SF) \
@@ -376,7 +397,7 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
   (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw); (void)hipFree(h->d_twist);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_runs); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
   if (h->h_out) (void)hipHostFree(h->h_out);
   delete h;
 }
@@ -438,7 +459,8 @@ const char *lora_hip_demod_kernel_name(const lora_hip_demod_t *h) { return h ? h
 static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, KParams &p,
                      const lora_win_desc *desc, size_t n_win, uint16_t *max_idx, float *max_val, unsigned flags) {
   const bool iq_staged = flags & LORA_HIP_IQ_STAGED;
-  if (!h || (!iq && n_samples && !iq_staged) || (n_win && (!max_idx || !max_val))) return LORA_HIP_EINVAL;
+  const bool no_val = (flags & LORA_HIP_NO_VAL) && !(flags & LORA_HIP_OUT_ON_DEVICE);
+  if (!h || (!iq && n_samples && !iq_staged) || (n_win && (!max_idx || (!max_val && !no_val)))) return LORA_HIP_EINVAL;
   if (iq_staged && (n_samples > h->staged_n || (flags & LORA_HIP_IQ_ON_DEVICE))) return LORA_HIP_EINVAL;
   if (n_win > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
   const bool iq_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
@@ -496,9 +518,16 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   if ((rc = launch(h, p, h->d_ticket)) != LORA_HIP_OK) return rc;
   if (!out_dev) {
     const size_t idx_off = n_win * 4;
-    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, n_win * 6, hipMemcpyDeviceToHost, h->stream));
+    if (flags & LORA_HIP_OUT_PINNED) {
+      if (!no_val) HIP_TRY(h, hipMemcpyAsync(max_val, h->d_out, n_win * 4, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(max_idx, h->d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      return LORA_HIP_OK;
+    }
+    if (no_val) HIP_TRY(h, hipMemcpyAsync(h->h_out + idx_off, h->d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, h->stream));
+    else HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, n_win * 6, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    memcpy(max_val, h->h_out, n_win * 4);
+    if (!no_val) memcpy(max_val, h->h_out, n_win * 4);
     memcpy(max_idx, h->h_out + idx_off, n_win * 2);
     return LORA_HIP_OK;
   }
@@ -530,6 +559,54 @@ int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c32 *iq, size_t
   p.pos0 = pos0; p.stride = stride; p.off0 = chirp_off; p.off_step = chirp_off_step; p.kind = kind;
   return run_batch(h, iq, n_samples, p, nullptr, count, max_idx, max_val, flags);
 }
+
+int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, const lora_win_run *runs,
+                              size_t n_runs, uint16_t *max_idx, float *max_val, unsigned flags) {
+  if (!h || (n_runs && !runs)) return LORA_HIP_EINVAL;
+  if (flags & (LORA_HIP_DESC_ON_DEVICE | LORA_HIP_ASYNC)) return LORA_HIP_EINVAL;   // the run list is host memory
+  if (n_runs > 0x7FFFFFFFull) return LORA_HIP_EINVAL;
+  std::vector<RunDev> rd;
+  uint64_t total = 0;
+  try {
+    rd.reserve(n_runs);
+    for (size_t r = 0; r < n_runs; r++) {
+      const lora_win_run &u = runs[r];
+      if (u.kind > LORA_WIN_SFD || u.chirp_off >= h->n || u.chirp_off_step >= h->n) return LORA_HIP_EINVAL;
+      if (u.count == 0) continue;
+      if (u.pos0 > n_samples || n_samples - u.pos0 < h->n) return LORA_HIP_EINVAL;
+      if (u.count > 1 && u.stride != 0 && (uint64_t)(u.count - 1) > (n_samples - u.pos0 - h->n) / u.stride) return LORA_HIP_EINVAL;
+      rd.push_back(RunDev{u.pos0, u.stride, (unsigned)total, u.chirp_off, u.chirp_off_step, u.kind});
+      total += u.count;
+      if (total > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
+    }
+  } catch (const std::bad_alloc &) { return LORA_HIP_ENOMEM; }
+  if (total == 0) return LORA_HIP_OK;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  int rc;
+  if ((rc = grow(h, &h->d_runs, &h->cap_runs, rd.size() * sizeof(RunDev))) != LORA_HIP_OK) return rc;
+  if ((rc = grow(h, reinterpret_cast<unsigned char **>(&h->d_desc), &h->cap_desc, (size_t)total * sizeof(lora_win_desc))) != LORA_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->d_runs, rd.data(), rd.size() * sizeof(RunDev), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));          // rd is pageable and goes out of scope
+  hipLaunchKernelGGL(expand_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                     reinterpret_cast<const RunDev *>(h->d_runs), (unsigned)rd.size(), (unsigned)total, h->n - 1,
+                     reinterpret_cast<lora_hip::WinDesc *>(h->d_desc));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "expand_runs launch");
+  KParams p;
+  memset(&p, 0, sizeof p);
+  return run_batch(h, iq, n_samples, p, reinterpret_cast<const lora_win_desc *>(h->d_desc), (size_t)total, max_idx, max_val,
+                   flags | LORA_HIP_DESC_ON_DEVICE);
+}
+
+int lora_hip_host_alloc(void **p, size_t bytes) {
+  if (!p) return LORA_HIP_EINVAL;
+  *p = nullptr;
+  hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { *p = nullptr; return LORA_HIP_ENOMEM; }
+  return LORA_HIP_OK;
+}
+void lora_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq_dev, size_t n_samples, uint64_t pos0,
                                          uint64_t stride, size_t count, unsigned chirp_off, unsigned chirp_off_step,

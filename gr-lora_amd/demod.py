@@ -22,7 +22,7 @@ class demod:
     name = "demod"                       # gr::block("demod", ...), lib/demod_impl.cc:58
     out_port = "out"                     # pmt::mp("out"), lib/demod_impl.cc:74
 
-    def __init__(self, spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0):
+    def __init__(self, spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0, plan=None):
         # asserts of lib/demod_impl.cc:70-72 (compiled out in the reference's Release build)
         if not (5 < spreading_factor < 13):
             raise ValueError("spreading_factor must be in 6..12")
@@ -37,14 +37,23 @@ class demod:
         if rc:
             self._h = None
             raise capi.LoraHipError(rc)
+        if plan is not None:                      # lora_demod_core_set_plan: 0 on demand, 1 long inputs, 2 always
+            rc = capi.lib().lora_demod_core_set_plan(self._h, int(plan))
+            if rc:
+                raise capi.LoraHipError(rc)
+        # PDUs are collected inside the block and fetched once per work() call: a ctypes callback per PDU costs more
+        # than the block spends on a packet
+        rc = capi.lib().lora_demod_core_set_collect(self._h, 1)
+        if rc:
+            raise capi.LoraHipError(rc)
         self._handlers = []
         self._pending = []
         self._trace = None
-        self._cb = capi.PDU_CB(self._on_pdu)     # keep the callback object alive
+        self._cb = capi.PDU_CB(0)                # NULL: no per-PDU callback
 
     @staticmethod
-    def make(spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0):
-        return demod(spreading_factor, low_data_rate, beta, fft_factor, device)
+    def make(spreading_factor=8, low_data_rate=False, beta=25.0, fft_factor=2, device=0, plan=None):
+        return demod(spreading_factor, low_data_rate, beta, fft_factor, device, plan)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -63,11 +72,23 @@ class demod:
         """handler(pdu) is called for every PDU published on port "out"."""
         self._handlers.append(handler)
 
-    def _on_pdu(self, _user, syms, n):
-        pdu = ({}, np.ctypeslib.as_array(syms, (n,)).copy() if n else np.zeros(0, np.uint16))
-        self._pending.append(pdu)
-        for h in self._handlers:
-            h(pdu)
+    def _fetch_pdus(self):
+        """The PDUs of the last work() call, as (meta, u16vector) pairs like pmt::cons(make_dict(), init_u16vector), :420-422;
+        subscribed handlers see each of them, in order."""
+        syms, offs, n = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        rc = capi.lib().lora_demod_core_collected(self._h, C.byref(syms), C.byref(offs), C.byref(n))
+        if rc:
+            raise capi.LoraHipError(rc)
+        self._pending = []
+        if n.value:
+            o = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_uint64)), (n.value + 1,))
+            total = int(o[-1])
+            flat = np.ctypeslib.as_array(C.cast(syms, C.POINTER(C.c_uint16)), (total,)).copy() if total else np.zeros(0, np.uint16)
+            ol = o.tolist()
+            self._pending = [({}, flat[ol[k]:ol[k + 1]]) for k in range(n.value)]
+        for pdu in self._pending:
+            for h in self._handlers:
+                h(pdu)
 
     def enable_trace(self, max_rows):
         self._trace = np.zeros(max_rows, capi.CORE_TRACE_DTYPE)
@@ -102,16 +123,24 @@ class demod:
             assert samples.dtype == torch.complex64 and samples.is_contiguous()
             cur = torch.cuda.current_stream(samples.device)
             if cur.cuda_stream:
-                capi.lib().lora_demod_core_set_stream(self._h, C.c_void_p(cur.cuda_stream))
+                rc = capi.lib().lora_demod_core_set_stream(self._h, C.c_void_p(cur.cuda_stream))
             else:       # torch's default stream is the null stream, which the C ABI cannot name: wait for the producer
                 cur.synchronize()
-                capi.lib().lora_demod_core_set_stream(self._h, None)
+                rc = capi.lib().lora_demod_core_set_stream(self._h, None)
+            if rc:
+                raise capi.LoraHipError(rc)
             rc = capi.lib().lora_demod_core_work_device(self._h, samples.data_ptr(), samples.numel(), self._cb, None)
+            self._fetch_pdus()            # PDUs completed before an error are still reported
             if rc:
                 raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
             return [p[1] for p in self._pending]
         x = np.ascontiguousarray(samples, np.complex64)
+        # host samples run on the block's own stream: a torch stream bound by an earlier device call may be gone by now
+        rc = capi.lib().lora_demod_core_set_stream(self._h, None)
+        if rc:
+            raise capi.LoraHipError(rc)
         rc = capi.lib().lora_demod_core_work(self._h, x.ctypes.data, len(x), self._cb, None)
+        self._fetch_pdus()
         if rc:
             raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
         return [p[1] for p in self._pending]
@@ -120,4 +149,6 @@ class demod:
     def stats(self):
         L = capi.lib()
         return dict(calls=int(L.lora_demod_core_calls(self._h)), windows=int(L.lora_demod_core_windows(self._h)),
-                    launches=int(L.lora_demod_core_launches(self._h)), state=int(L.lora_demod_core_state(self._h)))
+                    launches=int(L.lora_demod_core_launches(self._h)), state=int(L.lora_demod_core_state(self._h)),
+                    plans=int(L.lora_demod_core_plans(self._h)), replans=int(L.lora_demod_core_replans(self._h)),
+                    on_demand=int(L.lora_demod_core_on_demand(self._h)), rollbacks=int(L.lora_demod_core_rollbacks(self._h)))

@@ -69,6 +69,12 @@ LORA_HIP_API int lora_demod_core_work(lora_demod_core_t *c, const lora_c32 *in, 
  * call is made, or be produced on the stream given to lora_demod_core_set_stream. */
 LORA_HIP_API int lora_demod_core_work_device(lora_demod_core_t *c, const lora_c32 *in_device, size_t n_in,
                                              lora_pdu_cb cb, void *user);
+/* PDUs without a callback per PDU (a foreign-function callback costs more than the block spends on a packet): with
+ * collecting on, each work() call also keeps its PDUs inside the block -- PDU i is symbols[offsets[i] .. offsets[i+1]) --
+ * until the next work(), reset() or set_collect() call.  cb may then be NULL. */
+LORA_HIP_API int lora_demod_core_set_collect(lora_demod_core_t *c, int on);
+LORA_HIP_API int lora_demod_core_collected(const lora_demod_core_t *c, const uint16_t **symbols,
+                                           const uint64_t **offsets, size_t *n_pdus);
 /* Run the block's GPU work on a caller-owned hipStream_t (void*); NULL restores the block's own stream. */
 LORA_HIP_API int lora_demod_core_set_stream(lora_demod_core_t *c, void *hip_stream);
 
@@ -86,6 +92,22 @@ LORA_HIP_API int lora_demod_core_set_stream(lora_demod_core_t *c, void *hip_stre
  * of N/16.  The arrays are copied.  Results that never match a call are simply not used. */
 LORA_HIP_API int lora_demod_core_preload(lora_demod_core_t *c, uint64_t start, size_t count,
                                          const uint16_t *idx, const float *val);
+
+/* Planned evaluation.  A long input is not evaluated one packet at a time: per work() call the block sweeps the whole
+ * N/16 lattice for preambles (all 16 phases), evaluates every SFD search the preamble rule (:247-273) can start, dry-runs
+ * the state machine to find the header/payload windows, evaluates those, and only then runs the state machine for
+ * real -- a fixed number of launches whatever the number of packets; whatever the plan did not foresee is evaluated on
+ * demand.  The PDUs and the trace are the same either way (a plan only chooses which windows are evaluated early).
+ * mode 0: off (every window on demand, in speculative sweeps); 1 (default): inputs of at least 128 symbols;
+ * 2: every input.  The environment variable LORA_CORE_PLAN sets the default of new blocks. */
+LORA_HIP_API int lora_demod_core_set_plan(lora_demod_core_t *c, int mode);
+/* plans started, READ stages redone after a surprise, windows that had to be evaluated on demand (each = one launch) */
+LORA_HIP_API uint64_t lora_demod_core_plans(const lora_demod_core_t *c);
+LORA_HIP_API uint64_t lora_demod_core_replans(const lora_demod_core_t *c);
+LORA_HIP_API uint64_t lora_demod_core_on_demand(const lora_demod_core_t *c);
+/* times the first pass of a plan met a header/payload window whose real maximum fell on the other side of the squelch
+ * threshold than predicted: the block then resumes from the S_RESET call before that packet, evaluating on demand */
+LORA_HIP_API uint64_t lora_demod_core_rollbacks(const lora_demod_core_t *c);
 
 /* Optional per-call trace: rows are appended to `rows` (caller-owned) up to max_rows; the number
  * of calls so far (may exceed max_rows) is returned by lora_demod_core_calls(). */

@@ -52,8 +52,12 @@ enum {
   LORA_HIP_DESC_ON_DEVICE = 4,  /* desc is a device pointer */
   LORA_HIP_ASYNC = 8,           /* do not synchronise the handle's stream before returning
                                    (only valid when every buffer named above is on the device) */
-  LORA_HIP_IQ_STAGED = 16       /* iq is ignored: use the samples last given to
+  LORA_HIP_IQ_STAGED = 16,      /* iq is ignored: use the samples last given to
                                    lora_hip_demod_stage_iq (n_samples must not exceed them) */
+  LORA_HIP_OUT_PINNED = 32,     /* max_idx / max_val are page-locked host memory (lora_hip_host_alloc): the results
+                                   are copied straight into them instead of through the handle's own pinned mirror */
+  LORA_HIP_NO_VAL = 64          /* max_val may be NULL and is not written (host outputs only): half the copy back
+                                   for callers that need the bins only, like the SFD search (demod_impl.cc:322) */
 };
 
 /* one symbol window: N = 2^sf samples starting at iq[pos] */
@@ -120,6 +124,30 @@ LORA_HIP_API int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c3
                                               size_t count, unsigned chirp_off,
                                               unsigned chirp_off_step, unsigned kind,
                                               uint16_t *max_idx, float *max_val, unsigned flags);
+
+/*
+ * Several strided sweeps in ONE launch: run r contributes `count` windows at pos0 + i*stride with chirp offset
+ * (chirp_off + i*chirp_off_step) mod N, and the results of all runs lie back to back in run order.  This is what lets
+ * a host-side block evaluate every SFD search (:295-357) or every header/payload read (:363-413) of a long input in
+ * one launch instead of one per packet.  A small kernel expands the runs into window descriptors in HBM, then the
+ * same kernel as lora_hip_demod_batch runs over them.  Runs are validated on the host like host descriptors.
+ */
+typedef struct {
+  uint64_t pos0;            /* first window                                   */
+  uint32_t stride;          /* samples between windows                        */
+  uint32_t count;           /* windows in this run                            */
+  uint16_t chirp_off;       /* chirp offset of the first window, < N          */
+  uint16_t chirp_off_step;  /* added per window, mod N                        */
+  uint8_t  kind;            /* LORA_WIN_UP / LORA_WIN_SFD                     */
+  uint8_t  reserved[3];
+} lora_win_run;             /* 24 bytes */
+LORA_HIP_API int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples,
+                                           const lora_win_run *runs, size_t n_runs,
+                                           uint16_t *max_idx, float *max_val, unsigned flags);
+
+/* Page-locked host memory for LORA_HIP_OUT_PINNED result buffers (hipHostMalloc / hipHostFree). */
+LORA_HIP_API int lora_hip_host_alloc(void **p, size_t bytes);
+LORA_HIP_API void lora_hip_host_free(void *p);
 
 /*
  * lora_hip_demod_batch_strided for callers that cannot allocate.  It has no counterpart in the reference: it is
