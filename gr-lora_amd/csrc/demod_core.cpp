@@ -123,12 +123,19 @@ struct Snap { uint64_t pos, calls; size_t pdus; };
 // REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR + 1 entries
 template <unsigned CAP>
 struct Hist {
-  unsigned short v[CAP + 1]; unsigned n = 0;
+  // entries live at buf[head .. head + n): a push writes in front of them; when the front is reached they move back to
+  // the end of the array, once per kSlack pushes
+  static constexpr unsigned kSlack = 224;
+  unsigned short buf[CAP + 1 + kSlack]; unsigned head = kSlack, n = 0;
   size_t size() const { return n; }
-  void clear() { n = 0; }
-  void push_front(unsigned short x) { memmove(v + 1, v, n * sizeof(unsigned short)); v[0] = x; n++; }
+  void clear() { n = 0; head = kSlack; }
+  void push_front(unsigned short x) {
+    if (head == 0) { memmove(buf + kSlack, buf, n * sizeof(unsigned short)); head = kSlack; }
+    buf[--head] = x; n++;
+  }
   void pop_back() { n--; }
-  unsigned short operator[](size_t i) const { return v[i]; }
+  unsigned short operator[](size_t i) const { return buf[head + i]; }
+  const unsigned short *data() const { return buf + head; }
 };
 
 // everything general_work reads and writes between calls (demod_impl.h:43-70) plus the read index: a dry run saves and
@@ -412,8 +419,15 @@ int plan_sfd(lora_demod_core *c) {
       PRun &b = L.back();
       const uint64_t blo = (b.start - P.a_start) / step;
       if (lo <= blo + b.count) {                           // overlaps or touches the last sweep of this phase
-        if (hi > blo + b.count) { total += (size_t)(hi - blo - b.count); b.count = (uint32_t)(hi - blo); }
-        continue;
+        // An attempt entered later in the same preamble locks at the same place or not at all: the sweep grows by one
+        // call beyond what its first attempt can use, not by a full attempt per position (the rest, if ever asked
+        // for, is evaluated on demand)
+        const uint64_t cap = blo + kSfdSpan + OVERLAP_FACTOR;
+        if (hi > cap && lo < cap) hi = cap;
+        if (lo < cap) {
+          if (hi > blo + b.count) { total += (size_t)(hi - blo - b.count); b.count = (uint32_t)(hi - blo); }
+          continue;
+        }
       }
     }
     PRun r;
@@ -532,25 +546,34 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   // where the real run resumes: the last S_RESET call, or one before the first prediction that did not hold
   bool from_start = c->snaps.empty();
   Snap rb = from_start ? Snap{0, saved_calls, 0} : c->snaps.back();
-  size_t cur = 0, k = 0;
-  for (const Patch &pt : c->patches) {
-    if (pt.row >= rb.calls) break;
-    const bool found = planned_find(P.rd, cur, pt.pos, pt.off, n, &k);
-    if (found && (!(P.r_val.p[k] > c->d_threshold)) == (pt.sq != 0)) continue;
-    c->n_rollbacks++;
-    from_start = true; rb = Snap{0, saved_calls, 0};
-    for (size_t s = c->snaps.size(); s-- > 0;)
-      if (c->snaps[s].calls <= pt.row) { rb = c->snaps[s]; from_start = false; break; }
-    break;
-  }
-  cur = 0;
-  for (const Patch &pt : c->patches) {
-    if (pt.row >= rb.calls) break;
-    if (!planned_find(P.rd, cur, pt.pos, pt.off, n, &k)) break;            // (checked above)
-    const unsigned idx = P.r_idx.p[k];
-    const unsigned sym = (n + idx / F - pt.pre / F) % n;                   // :373, :398-401
-    c->pdu_syms[pt.flat] = (unsigned short)(pt.div4 ? sym / 4 : sym);
-    if (c->trace && pt.row < c->max_trace) { c->trace[pt.row].idx = (uint16_t)idx; c->trace[pt.row].val = P.r_val.p[k]; }
+  // one pass over the predicted calls, in the order they were made (= the order of the READ sweeps): check the squelch
+  // decision, then fill in the bin.  A decision that does not hold ends the pass: the state machine goes back to the
+  // S_RESET call before that packet (what was filled in behind that call is never delivered and is overwritten).
+  {
+    size_t r = 0;
+    const unsigned sh = __builtin_ctz(n);
+    for (const Patch &pt : c->patches) {
+      if (pt.row >= rb.calls) break;
+      while (r < P.rd.size() && !(P.rd[r].off0 == pt.off && pt.pos >= P.rd[r].start &&
+                                  pt.pos < P.rd[r].start + ((uint64_t)P.rd[r].count << sh))) r++;
+      bool ok = r < P.rd.size() && ((pt.pos - P.rd[r].start) & (n - 1)) == 0;
+      size_t k = 0;
+      if (ok) {
+        k = P.rd[r].at + (size_t)((pt.pos - P.rd[r].start) >> sh);
+        ok = (!(P.r_val.p[k] > c->d_threshold)) == (pt.sq != 0);
+      }
+      if (!ok) {
+        c->n_rollbacks++;
+        from_start = true; rb = Snap{0, saved_calls, 0};
+        for (size_t s = c->snaps.size(); s-- > 0;)
+          if (c->snaps[s].calls <= pt.row) { rb = c->snaps[s]; from_start = false; break; }
+        break;
+      }
+      const unsigned idx = P.r_idx.p[k];
+      const unsigned sym = (n + idx / F - pt.pre / F) % n;                   // :373, :398-401
+      c->pdu_syms[pt.flat] = (unsigned short)(pt.div4 ? sym / 4 : sym);
+      if (c->trace && pt.row < c->max_trace) { c->trace[pt.row].idx = (uint16_t)idx; c->trace[pt.row].val = P.r_val.p[k]; }
+    }
   }
   const double t3 = now_s();
   for (size_t i = 0; i < rb.pdus; i++) {
@@ -800,12 +823,19 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
         if (c->d_sfd_history.size() > REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR) {
           c->d_sfd_history.pop_back();
           c->d_sfd_idx = c->d_sfd_history[0];
-          int worst = 0;                                           // same test as the reference's loop, without branches
-          for (int i = 1; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++) {
-            const int dv = abs(int(c->d_sfd_idx) - int(c->d_sfd_history.v[i]));
-            worst = dv > worst ? dv : worst;
+          // the reference's test (every older entry within the tolerance of the newest); the previous window alone
+          // settles it for almost every window, the rest is one pass without branches
+          const unsigned short *hs = c->d_sfd_history.data();
+          const int tol = int(F) * LORA_SFD_TOLERANCE;
+          sfd_found = !(abs(int(c->d_sfd_idx) - int(hs[1])) > tol);
+          if (sfd_found) {
+            int worst = 0;
+            for (int i = 2; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++) {
+              const int dv = abs(int(c->d_sfd_idx) - int(hs[i]));
+              worst = dv > worst ? dv : worst;
+            }
+            sfd_found = !(worst > tol);
           }
-          sfd_found = !(worst > int(F) * LORA_SFD_TOLERANCE);
           if (sfd_found) {
             num_consumed = (ol * N) / c->d_overlaps + 5 * N / 4;   // skip last quarter chirp
             c->d_offset = (c->d_offset + (N / 4)) % N;
