@@ -34,13 +34,13 @@ EXPORTS = (
     # include/lora_demod_core.h
     "lora_demod_core_create", "lora_demod_core_destroy", "lora_demod_core_work", "lora_demod_core_set_trace",
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
-    "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset", "lora_demod_core_set_plan", "lora_demod_core_set_collect", "lora_demod_core_collected",
+    "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset", "lora_demod_core_set_plan", "lora_demod_core_seek", "lora_demod_core_idle_log", "lora_demod_core_set_collect", "lora_demod_core_collected",
     "lora_demod_core_plans", "lora_demod_core_replans", "lora_demod_core_on_demand", "lora_demod_core_rollbacks",
     # include/lora_hip_chan.h
     "lora_hip_chan_design_taps", "lora_hip_chan_create", "lora_hip_chan_destroy", "lora_hip_chan_set_stream",
     "lora_hip_chan_last_hip_error", "lora_hip_chan_reset", "lora_hip_chan_output_count", "lora_hip_chan_work",
     "lora_hip_chan_taps_per_filter", "lora_hip_chan_dec_rate", "lora_hip_chan_flt_rate", "lora_hip_chan_kernel_name",
-    "lora_hip_chan_force_general", "lora_hip_chan_phase_inc_effective", "lora_hip_chan_seek",
+    "lora_hip_chan_force_general", "lora_hip_chan_piece_limit", "lora_hip_chan_phase_inc_effective", "lora_hip_chan_seek",
     # include/lora_decode.h
     "lora_decode_max_bytes", "lora_decode_pdu",
 )
@@ -102,6 +102,8 @@ def lib():
     L.lora_demod_core_work.argtypes = [vp, vp, sz, PDU_CB, vp]; L.lora_demod_core_work.restype = i
     L.lora_demod_core_set_trace.argtypes = [vp, vp, sz]; L.lora_demod_core_set_trace.restype = i
     L.lora_demod_core_set_plan.argtypes = [vp, i]; L.lora_demod_core_set_plan.restype = i
+    L.lora_demod_core_seek.argtypes = [vp, u64]; L.lora_demod_core_seek.restype = i
+    L.lora_demod_core_idle_log.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]; L.lora_demod_core_idle_log.restype = i
     L.lora_demod_core_set_collect.argtypes = [vp, i]; L.lora_demod_core_set_collect.restype = i
     L.lora_demod_core_collected.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.lora_demod_core_collected.restype = i
     L.lora_hip_demod_batch_runs.argtypes = [vp, vp, sz, vp, sz, vp, vp, u]; L.lora_hip_demod_batch_runs.restype = i
@@ -114,6 +116,7 @@ def lib():
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
     L.lora_demod_core_reset.argtypes = [vp]; L.lora_demod_core_reset.restype = i
     L.lora_demod_core_preload.argtypes = [vp, u64, sz, vp, vp]; L.lora_demod_core_preload.restype = i
+    L.lora_hip_chan_piece_limit.argtypes = [u]; L.lora_hip_chan_piece_limit.restype = sz
     L.lora_hip_chan_design_taps.argtypes = [d, u, d, vp, sz, C.POINTER(sz)]; L.lora_hip_chan_design_taps.restype = i
     L.lora_hip_chan_create.argtypes = [C.POINTER(vp), i, d, f, vp, sz, u]; L.lora_hip_chan_create.restype = i
     L.lora_hip_chan_destroy.argtypes = [vp]; L.lora_hip_chan_destroy.restype = None

@@ -150,6 +150,7 @@ struct WalkState {
   unsigned d_sync_recovery_counter = 0;
   std::vector<unsigned short> d_symbols;
   uint64_t pos = 0;
+  uint64_t n_pdus = 0;          // PDUs emitted on this stream so far
 };
 
 struct lora_demod_core : WalkState {
@@ -177,6 +178,8 @@ struct lora_demod_core : WalkState {
   bool deferred = false, pred = false;
   std::vector<Patch> patches; std::vector<Snap> snaps;
   std::vector<uint16_t> pdu_syms; std::vector<size_t> pdu_off;
+  // every maximal run of consecutive S_DETECT_PREAMBLE calls (lora_demod_core_idle_log); calls0 = call number of its first
+  std::vector<lora_core_idle> idle; std::vector<uint64_t> idle_calls0;
   bool collect = false;                                        // lora_demod_core_set_collect
   std::vector<uint16_t> col_syms; std::vector<uint64_t> col_off;
   long fault_at = -1; uint64_t n_pred = 0, n_rollbacks = 0;    // LORA_CORE_FAULT: test hook, mispredict that window
@@ -525,7 +528,10 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
     }
   } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   c->shadow = false; c->deferred = false;
-  auto to_start = [&]() { static_cast<WalkState &>(*c) = saved; c->n_calls = saved_calls; };
+  auto to_start = [&]() {
+    static_cast<WalkState &>(*c) = saved; c->n_calls = saved_calls;
+    while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
+  };
   if (rc != LORA_HIP_OK && rc != kShadowStop) { to_start(); return rc; }
   const uint64_t end = c->base + c->total();
   for (PRun &r : c->needs) {
@@ -581,7 +587,8 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
     deliver(c, cb, user, c->pdu_syms.data() + b, e - b);
   }
   if (from_start) to_start();
-  else { c->d_state = LORA_S_RESET; c->pos = rb.pos; c->n_calls = rb.calls; }
+  else { c->d_state = LORA_S_RESET; c->pos = rb.pos; c->n_calls = rb.calls; c->n_pdus = saved.n_pdus + rb.pdus; }
+  while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
   P.rd_cur = 0;
   c->t_stage[3] += t3 - t2; c->t_cb += now_s() - t3;
   return LORA_HIP_OK;
@@ -773,6 +780,10 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
   const unsigned off = (c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) ? c->d_offset : 0;
   float max_val = 0.f;
   if (c->deferred && c->d_state == LORA_S_RESET) c->snaps.push_back(Snap{c->pos, c->n_calls, c->pdu_off.size()});
+  if (c->d_state == LORA_S_DETECT_PREAMBLE && (!c->shadow || c->deferred)) {
+    if (!c->idle.empty() && c->idle.back().last + N == c->pos) c->idle.back().last = c->pos;
+    else { c->idle.push_back(lora_core_idle{c->pos, c->pos, c->n_pdus}); c->idle_calls0.push_back(c->n_calls); }
+  }
   c->pred = false;
   int rc = get_up(c, c->pos, off, &max_index, &max_val);
   if (rc) return rc;
@@ -868,6 +879,7 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       break;
 
     case LORA_S_OUT:                                                // :418-431
+      c->n_pdus++;
       if (c->deferred) {
         c->pdu_off.push_back(c->pdu_syms.size());
         c->pdu_syms.insert(c->pdu_syms.end(), c->d_symbols.begin(), c->d_symbols.end());
@@ -924,7 +936,8 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->d_sync_recovery_counter = 0;
   c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
   c->cur_in = nullptr; c->cur_n = 0;
-  c->base = 0; c->pos = 0;
+  c->base = 0; c->pos = 0; c->n_pdus = 0;
+  c->idle.clear(); c->idle_calls0.clear();
   c->up_runs.clear(); c->pre_runs.clear(); c->sfd_runs.clear();
   for (unsigned &m : c->sfd_misses) m = 0;
   for (uint64_t &m : c->sfd_last_miss) m = 0;
@@ -934,6 +947,22 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->plan.active = false; c->shadow = false; c->deferred = false;
   c->n_pred = 0; c->n_rollbacks = 0;
   c->err.clear();
+  return LORA_HIP_OK;
+}
+
+int lora_demod_core_seek(lora_demod_core_t *c, uint64_t pos) {
+  if (!c) return LORA_HIP_EINVAL;
+  if (pos % (c->d_num_symbols / OVERLAP_FACTOR)) return LORA_HIP_EINVAL;          // read indices stay on the N/16 lattice
+  const int rc = lora_demod_core_reset(c);
+  if (rc) return rc;
+  c->buf.clear();                        // no scheduler history: the next sample fed IS framed-stream index pos
+  c->base = pos; c->pos = pos;
+  return LORA_HIP_OK;
+}
+
+int lora_demod_core_idle_log(const lora_demod_core_t *c, const lora_core_idle **runs, size_t *n_runs) {
+  if (!c || !runs || !n_runs) return LORA_HIP_EINVAL;
+  *runs = c->idle.data(); *n_runs = c->idle.size();
   return LORA_HIP_OK;
 }
 

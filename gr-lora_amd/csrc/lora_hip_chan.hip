@@ -549,11 +549,15 @@ size_t frac_count(const lora_hip_chan *h, size_t n_in, unsigned long long *p0_ou
   return (size_t)hi;
 }
 
-const size_t kSchedChunk = (size_t)1 << 26;     // fallback positions are 32-bit: nfilts * chunk < 2^32
+// fallback positions (i_in*nfilts + j, run_recurrence) are 32-bit: the inputs of one piece must keep them below 2^32
+// for every nfilts create() accepts (a position is stored with j < nfilts, so it is below nfilts * piece <= 2^31)
+inline size_t sched_chunk(unsigned nfilts) { return (size_t)((1ull << 31) / (nfilts ? nfilts : 1)); }
 
 }  // namespace
 
 extern "C" {
+
+size_t lora_hip_chan_piece_limit(unsigned nfilts) { return sched_chunk(nfilts); }
 
 int lora_hip_chan_design_taps(double rate, unsigned nfilts, double atten_db, float *taps, size_t cap, size_t *ntaps) {
   if (!ntaps || !(rate > 0.0) || nfilts == 0 || !(atten_db > 0.0) || (cap && !taps)) return LORA_HIP_EINVAL;
@@ -894,7 +898,7 @@ int lora_hip_chan_work(lora_hip_chan_t *h, const lora_c32 *in, size_t n_in, lora
     d_out = h->d_out;
   }
   // the fallback form carries 32-bit positions: long inputs go through in pieces (any chunking gives the same stream)
-  const size_t piece = h->frac ? n_in : kSchedChunk;
+  const size_t piece = h->frac ? n_in : sched_chunk(h->nfilts);
   size_t done_in = 0, done_out = 0;
   while (done_in < n_in) {
     const size_t n = (n_in - done_in < piece) ? n_in - done_in : piece;

@@ -105,6 +105,24 @@ class demod:
             raise capi.LoraHipError(rc)
         self._pending = []
 
+    def seek(self, pos):
+        """lora_demod_core_seek: a new stream that starts at framed-stream index pos in S_RESET; the next samples fed
+        are framed-stream samples from pos on (no history zeros in front)."""
+        rc = capi.lib().lora_demod_core_seek(self._h, int(pos))
+        if rc:
+            raise capi.LoraHipError(rc)
+        self._pending = []
+
+    def idle_log(self):
+        """lora_demod_core_idle_log as an (k, 3) uint64 array: first index, last index, PDUs emitted before."""
+        p, n = C.c_void_p(), C.c_size_t(0)
+        rc = capi.lib().lora_demod_core_idle_log(self._h, C.byref(p), C.byref(n))
+        if rc:
+            raise capi.LoraHipError(rc)
+        if not n.value:
+            return np.zeros((0, 3), np.uint64)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), (n.value, 3)).copy()
+
     def preload(self, start, idx, val):
         """lora_demod_core_preload: up-path results (offset 0) of the windows starting at framed-stream
         index start + k*N, produced ahead of time (shard.sharded_detect_sweep)."""

@@ -55,7 +55,16 @@ int channelizer_hip_impl::general_work(int noutput_items, gr_vector_int &ninput_
   size_t produced = 0;
   const int rc = lora_hip_chan_work(d_chan, static_cast<const lora_c32 *>(input_items[0]), lo,
                                     static_cast<lora_c32 *>(output_items[0]), (size_t)noutput_items, &produced, 0);
-  if (rc != LORA_HIP_OK) std::cerr << "lora_hip_chan_work: " << lora_hip_strerror(rc) << " " << lora_hip_chan_last_hip_error(d_chan) << std::endl;
+  if (rc != LORA_HIP_OK) {
+    // nothing is consumed and the flowgraph stops: dropping the input would hand the demod a stream with a hole in it
+    std::cerr << "lora_hip_chan_work: " << lora_hip_strerror(rc) << " " << lora_hip_chan_last_hip_error(d_chan) << std::endl;
+    return WORK_DONE;
+  }
+  if (lo == 0 && ninput_items[0] > 0) {
+    // not even one input's outputs fit (rate > 1): ask the scheduler for more output space instead of spinning
+    set_output_multiple((int)std::ceil(d_rate) + 1);
+    return 0;
+  }
   consume_each((int)lo);
   return (int)produced;
 }

@@ -41,7 +41,11 @@ int demod_hip_impl::general_work(int noutput_items, gr_vector_int &ninput_items,
                                  gr_vector_const_void_star &input_items, gr_vector_void_star &) {
   const lora_c32 *in = static_cast<const lora_c32 *>(input_items[0]);
   const int rc = lora_demod_core_work(d_core, in, (size_t)ninput_items[0], &demod_hip_impl::on_pdu, this);
-  if (rc != LORA_HIP_OK) std::cerr << "lora_demod_core_work: " << lora_demod_core_last_error(d_core) << std::endl;
+  if (rc != LORA_HIP_OK) {
+    // a failed call may have emitted some PDUs already; the samples are not consumed and the flowgraph stops
+    std::cerr << "lora_demod_core_work: " << lora_demod_core_last_error(d_core) << std::endl;
+    return WORK_DONE;
+  }
   consume_each(ninput_items[0]);
   return noutput_items;
 }

@@ -216,6 +216,171 @@ def demod_long_capture(samples, make_block, sf, sweep, dst=0):
     return pdus
 
 
+# ---- (ii-b) sharded replay: every rank demodulates its own time segment -----------------------------
+#
+# Design A above shards the 16-phase preamble sweep and leaves the state machine -- and with it the SFD searches, the
+# header/payload windows and the whole capture's host-to-device copy -- to one rank.  Here the state machine is sharded
+# too.  It rests on one property of the reference's block (lib/demod_impl.cc:214-273): at an S_RESET call everything
+# but the read index is cleared, and at an S_DETECT_PREAMBLE call the argmax history is the four windows before the read
+# index; so two blocks that make such a call at the same read index behave identically from there on, wherever each was
+# started.  A rank therefore starts a block at its segment's first sample (lora_demod_core_seek) once per lattice phase
+# the sequential block could be on, walks its segment plus an overlap, and logs when it is idle
+# (lora_demod_core_idle_log).  The phases collapse onto one trajectory as soon as a packet has been locked (the SFD lock
+# depends on the signal, not on the phase the search was entered on), so only a short prefix is walked 16 times.
+# Rank 0 then chains the segments: the trajectory that is the sequential block's so far, continued through its overlap,
+# is matched against the next segment's trajectories at the first read index where both are idle; PDUs before that
+# index come from the former, PDUs after it from the latter.  A segment for which no such index exists is walked again
+# from the last idle index of the chain (correct for any input; slower only then).  Nothing is exchanged between ranks
+# but the trajectories (PDUs and idle runs).
+
+def _join(ta, tb, n, min_pos):
+    """First read index >= min_pos at which both trajectories make an S_DETECT_PREAMBLE call (idle runs on the same
+    stride-N lattice that overlap) -> (pos, run index in ta, run index in tb) or None."""
+    ia, ib = ta["idle"], tb["idle"]
+    # runs are sorted and disjoint: skip those that end before min_pos
+    a = int(np.searchsorted(ia[:, 1], min_pos)) if len(ia) else 0
+    b = int(np.searchsorted(ib[:, 1], min_pos)) if len(ib) else 0
+    best = None
+    while a < len(ia) and b < len(ib):
+        fa, la = int(ia[a][0]), int(ia[a][1]); fb, lb = int(ib[b][0]), int(ib[b][1])
+        if (fa - fb) % n == 0:
+            p = max(fa, fb)
+            if p < min_pos:
+                p += -(-(min_pos - p) // n) * n
+            if p <= min(la, lb):
+                best = (p, a, b)
+                break
+        if la < lb:
+            a += 1
+        else:
+            b += 1
+    return best
+
+
+def _splice(head, tail, n, min_pos):
+    """The trajectory that follows `head` until the two are idle together, `tail` from there on; None if they never are."""
+    j = _join(head, tail, n, min_pos)
+    if j is None:
+        return None
+    p, a, b = j
+    keep = int(head["idle"][a][2])                    # PDUs head emitted before that idle run
+    drop = int(tail["idle"][b][2])
+    pdus = list(head["pdus"][:keep]) + list(tail["pdus"][drop:])
+    idle = [tuple(int(v) for v in r) for r in head["idle"][:a]]
+    if int(head["idle"][a][0]) < p:
+        idle.append((int(head["idle"][a][0]), p - n, keep))
+    idle.append((p, int(tail["idle"][b][1]), keep))
+    idle += [(int(r[0]), int(r[1]), int(r[2]) - drop + keep) for r in tail["idle"][b + 1:]]
+    return dict(pdus=pdus, idle=np.array(idle, np.uint64).reshape(-1, 3), end=tail["end"], joined_at=p)
+
+
+def segment_cuts(n_samples, sf, world_size):
+    """Framed-stream indices (multiples of N) at which the segments start, plus the end of the stream."""
+    n = 1 << sf
+    n_stream = 3 * n - 1 + n_samples
+    syms = n_stream // n
+    return [n * ((syms * r) // world_size) for r in range(world_size)] + [n_stream]
+
+
+def walk_segment(walker, sf, lo, hi, end, overlap_symbols, first):
+    """All trajectories of the segment [lo, hi) of the framed stream (end = its length).
+    walker(a, b) -> dict(pdus, idle (k,3) uint64, end=b): a block entered in S_RESET at framed index a, fed [a, b).
+    The first segment has one trajectory (the stream's true start); every other one has 16, one per lattice phase the
+    sequential block may arrive on: phase 0 walks the whole segment plus the overlap, the others only until they are
+    idle together with phase 0 (tried over the overlap first, then over twice as much, ...)."""
+    n, step = 1 << sf, (1 << sf) // LATTICE
+    stop = min(end, hi + overlap_symbols * n)
+    main = walker(lo, stop)
+    if first:
+        return [main]
+    out = [main]
+    for phase in range(1, LATTICE):
+        span = max(overlap_symbols, 64) * n
+        while True:
+            b = min(stop, lo + span)
+            w = walker(lo + phase * step, b) if lo + phase * step + 4 * n <= b else dict(pdus=[], idle=np.zeros((0, 3), np.uint64), end=b)
+            t = _splice(w, main, n, lo)
+            if t is not None or b >= stop:
+                out.append(t if t is not None else w)
+                break
+            span *= 2
+    return out
+
+
+def chain_segments(trajs, cuts, sf, walker=None):
+    """trajs[k] = walk_segment(...) of segment k, in order -> the sequential block's PDU list.
+    walker: used only for a segment none of whose trajectories is ever idle together with the chain so far."""
+    n = 1 << sf
+    cur = trajs[0][0]
+    fallbacks = 0
+    for k in range(1, len(trajs)):
+        best = None
+        for t in trajs[k]:
+            j = _join(cur, t, n, cuts[k])
+            if j is not None and (best is None or j[0] < best[0][0]):
+                best = (j, t)
+        if best is not None:
+            cur = _splice(cur, best[1], n, cuts[k])
+            continue
+        # never idle together: walk this segment again as the continuation of the chain
+        if walker is None:
+            raise RuntimeError(f"segment {k}: no trajectory joins the chain and no walker was given")
+        fallbacks += 1
+        if len(cur["idle"]):
+            a = len(cur["idle"]) - 1
+            p = int(cur["idle"][a][1])                    # the chain's last idle call: a block in S_RESET 5 calls earlier is there too
+            stop = trajs[k][0]["end"]
+            if p - 5 * n >= 0:
+                redo = walker(p - 5 * n, stop)
+                cur = _splice(cur, redo, n, p)
+                if cur is not None:
+                    continue
+        cur = walker(0, trajs[k][0]["end"])               # no idle call at all so far: the sequential run
+    return cur["pdus"], fallbacks
+
+
+class BlockWalker:
+    """walker() on a demod block (gr-lora_amd.demod): seek, feed the framed samples, read PDUs and idle log."""
+
+    def __init__(self, samples, sf, make_block, on_device=False):
+        self.samples, self.sf, self.blk, self.on_device = samples, sf, make_block(), on_device
+        self.walks = 0
+
+    def __call__(self, a, b):
+        self.blk.seek(a)
+        x = framed_slice(self.samples, self.sf, a, b)
+        if self.on_device:
+            import torch
+            x = torch.from_numpy(x).cuda()
+        pdus = self.blk.work(x)
+        self.walks += 1
+        return dict(pdus=pdus, idle=self.blk.idle_log(), end=b)
+
+    def close(self):
+        self.blk.close()
+
+
+def demod_long_capture_sharded(samples, walker, sf, overlap_symbols=1024, dst=0):
+    """Sharded replay end to end: every rank walks its own time segment, rank `dst` chains them and returns
+    (pdus, info); the others return None.  Without a process group one rank walks every segment in turn
+    (world_size segments when `walker` carries a `segments` attribute, else one)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if multi else (int(getattr(walker, "segments", 1)), 0)
+    cuts = segment_cuts(len(samples), sf, world)
+    end = cuts[-1]
+    if multi:
+        mine = walk_segment(walker, sf, cuts[rank], cuts[rank + 1], end, overlap_symbols, first=rank == 0)
+        gathered = [None] * world if rank == dst else None
+        dist.gather_object(mine, gathered, dst=dst)
+        if rank != dst:
+            return None
+    else:
+        gathered = [walk_segment(walker, sf, cuts[k], cuts[k + 1], end, overlap_symbols, first=k == 0) for k in range(world)]
+    pdus, fallbacks = chain_segments(gathered, cuts, sf, walker)
+    return pdus, dict(segments=world, fallbacks=fallbacks, trajectories=[len(t) for t in gathered])
+
+
 # ---- channeliser: time segments of one wideband capture (include/lora_hip_chan.h, lora_hip_chan_seek) ----------
 def channelize_segment(samples, chan, rank, world):
     """This rank's share of channelising one long capture: the contiguous segment my_range(len(samples), rank, world)

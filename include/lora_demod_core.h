@@ -109,6 +109,19 @@ LORA_HIP_API uint64_t lora_demod_core_on_demand(const lora_demod_core_t *c);
  * threshold than predicted: the block then resumes from the S_RESET call before that packet, evaluating on demand */
 LORA_HIP_API uint64_t lora_demod_core_rollbacks(const lora_demod_core_t *c);
 
+/* Sharded replay of one long capture (no counterpart in the reference).  The block's state is determined
+ * by its read index alone at every S_RESET call (:215-229 clears the rest) and at every S_DETECT_PREAMBLE call (the
+ * argmax history then holds the four windows before the read index, :207-212, :233-242): two blocks that make such a call
+ * at the same framed-stream index emit the same PDUs from there on.  So a GPU can demodulate a time segment on its own,
+ * started anywhere, and its output is the sequential block's from the first index at which both are idle together.
+ *   seek: like reset, but the stream starts at framed-stream index pos (a multiple of N/16) in S_RESET with no history
+ *   zeros: the first sample fed afterwards is framed-stream index pos (trace rows and preload use the same indices).
+ *   idle_log: every maximal run of consecutive S_DETECT_PREAMBLE calls since the last reset/seek, as first and last read
+ *   index (N apart) and the number of PDUs emitted before it; valid until the next call on the block. */
+typedef struct { uint64_t first, last, pdus_before; } lora_core_idle;
+LORA_HIP_API int lora_demod_core_seek(lora_demod_core_t *c, uint64_t pos);
+LORA_HIP_API int lora_demod_core_idle_log(const lora_demod_core_t *c, const lora_core_idle **runs, size_t *n_runs);
+
 /* Optional per-call trace: rows are appended to `rows` (caller-owned) up to max_rows; the number
  * of calls so far (may exceed max_rows) is returned by lora_demod_core_calls(). */
 LORA_HIP_API int lora_demod_core_set_trace(lora_demod_core_t *c, lora_core_trace *rows, size_t max_rows);

@@ -79,6 +79,15 @@ LORA_HIP_API double lora_hip_chan_phase_inc_effective(const lora_hip_chan_t *h);
  * 0, d_dec_rate = D * nfilts, D in 2..8, 10, 12, 16), "chan_arb_kernel" for other rates whose filter banks fit LDS,
  * "chan_general_kernel" otherwise */
 LORA_HIP_API const char *lora_hip_chan_kernel_name(const lora_hip_chan_t *h);
+/* Non-finite input.  pfb_arb_resampler_ccf multiplies exactly the taps_per_filter samples of an output's window.  The
+ * whole-number-decimation kernel pads every polyphase component with zero taps to a multiple of eight and sums over
+ * lanes that carry zero taps, so an Inf or NaN sample up to 8*D samples outside an output's true window still meets
+ * a zero tap (0*Inf = NaN) and that output becomes NaN where the reference's stays finite.  Finite input -- anything a
+ * receiver delivers -- is not affected; callers that must reproduce the reference on non-finite samples use
+ * lora_hip_chan_force_general. */
+/* Rates above nfilts keep per-output positions in 32 bits: work() feeds such inputs through in pieces of at most this
+ * many samples (2^31 / nfilts), which gives the same stream as one call. */
+LORA_HIP_API size_t lora_hip_chan_piece_limit(unsigned nfilts);
 /* developer knob: 1 = always run the general kernel (the one that follows the reference's summation order) */
 LORA_HIP_API int lora_hip_chan_force_general(lora_hip_chan_t *h, int on);
 

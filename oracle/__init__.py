@@ -184,6 +184,31 @@ class Demod:
         return pdus, (trace[:nc.value] if want_trace else None), nc.value, nf.value
 
 
+def _stream_framed(self, framed, pos0=0):
+    """The block over an already framed stream whose first sample is framed-stream index pos0, entered in S_RESET (what
+    the product's lora_demod_core_seek does).  Returns (pdus, trace) with trace positions in framed-stream indices."""
+    x = np.ascontiguousarray(framed, np.complex64)
+    max_calls = len(x) // max(1, self.N // 16) + 16
+    max_syms = len(x) // self.N + 16
+    syms = np.empty(max_syms, np.uint16); plen = np.empty(max_syms, np.uint32)
+    trace = np.zeros(max_calls, TRACE_DTYPE)
+    nc = C.c_size_t(0)
+    fn = lib().lo_demod_stream_framed
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                   C.POINTER(C.c_size_t)]
+    npdu = fn(self._h, _ptr(x), len(x), _ptr(syms), max_syms, _ptr(plen), max_syms, _ptr(trace), max_calls, C.byref(nc))
+    pdus, k = [], 0
+    for i in range(npdu):
+        pdus.append(syms[k:k + plen[i]].copy()); k += int(plen[i])
+    tr = trace[:nc.value].copy()
+    tr["pos"] += np.uint64(pos0)
+    return pdus, tr
+
+
+Demod.stream_framed = _stream_framed
+
+
 def time_stream(sf, ldr, beta, fft_factor, capture, reps=1, optimised=False):
     """cpu_baseline leg: seconds for `reps` passes of the faithful loop (or of its optimised variant);
     returns (sec, calls, ffts, pdus) per pass."""

@@ -836,6 +836,29 @@ size_t lo_demod_stream(lo_demod *d, const lo_c32 *capture, size_t n,
   return np;
 }
 
+/* The same loop over a stream that is framed already (test stand-in for the product's lora_demod_core_seek): framed[0] is
+ * the first sample the block reads, in S_RESET; trace positions are relative to framed[0]. */
+size_t lo_demod_stream_framed(lo_demod *d, const lo_c32 *framed, size_t n,
+                              uint16_t *sym_out, size_t max_syms, uint32_t *pdu_len, size_t max_pdus,
+                              lo_trace *trace, size_t max_trace, size_t *n_calls)
+{
+  lo_sink sink = { sym_out, max_syms, 0, pdu_len, max_pdus, 0 };
+  state_reset_members(d);
+  const size_t N = d->d_num_symbols;
+  const size_t need = N + DEMOD_HISTORY_DEPTH * N - 1;
+  size_t pos = 0, calls = 0;
+  while (pos + need <= n) {
+    lo_trace row; memset(&row, 0, sizeof row);
+    row.pos = pos;
+    unsigned short c = general_work(d, framed + pos, &sink, &row);
+    if (trace && calls < max_trace) trace[calls] = row;
+    calls++;
+    pos += c;
+  }
+  if (n_calls) *n_calls = calls;
+  return sink.n_pdus;
+}
+
 static double demod_time(int optimised, unsigned sf, int ldr, float beta, unsigned fft_factor,
                          const lo_c32 *capture, size_t n, unsigned reps,
                          size_t *n_calls, size_t *n_ffts, size_t *n_pdus)

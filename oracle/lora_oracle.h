@@ -104,6 +104,10 @@ size_t lo_demod_stream(lo_demod *d, const lo_c32 *capture, size_t n,
                        uint16_t *sym_out, size_t max_syms, uint32_t *pdu_len, size_t max_pdus,
                        lo_trace *trace, size_t max_trace, size_t *n_calls, size_t *n_ffts);
 
+/* the same loop over an already framed stream (no history zeros are put in front): framed[0] is read first, in S_RESET */
+size_t lo_demod_stream_framed(lo_demod *d, const lo_c32 *framed, size_t n,
+                              uint16_t *sym_out, size_t max_syms, uint32_t *pdu_len, size_t max_pdus,
+                              lo_trace *trace, size_t max_trace, size_t *n_calls);
 /* CPU baseline leg: same loop as lo_demod_stream (faithful: 3 allocations per call, the dead
  * down-path multiply, memset+memcpy zero padding, full M-point FFT, scalar argmax), repeated
  * over the capture `reps` times on a fresh instance state; returns seconds of wall time and

@@ -102,3 +102,15 @@ def test_synth_matches_mod_layout(g):
     for sf in (7, 9):
         syms = oracle.random_symbols(sf, 11, 5)
         assert np.array_equal(synth.modulate(sf, syms, 0x12), oracle.modulate(sf, syms, 0x12))
+
+
+def test_channeliser_piece_limit_keeps_positions_in_32_bits(g):
+    """Fallback schedule of the channeliser (rate > nfilts): a position is i_in*nfilts + j with j < nfilts and is kept
+    in 32 bits, so the pieces work() cuts a long input into must satisfy nfilts * piece <= 2^31 for every nfilts that
+    lora_hip_chan_create accepts (1..1024)."""
+    lib = g.capi.lib()
+    for nfilts in list(range(1, 70)) + [127, 128, 500, 1023, 1024]:
+        piece = lib.lora_hip_chan_piece_limit(nfilts)
+        assert piece >= 1 << 21
+        assert nfilts * piece <= 1 << 31
+        assert nfilts * (piece + 1) > (1 << 31) - nfilts       # and no smaller than it has to be

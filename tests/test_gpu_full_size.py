@@ -32,5 +32,5 @@ def test_configs3_full_size(run_configs):
 def test_configs4_full_size(run_configs):
     r = run_configs.cfg4()
     assert r["packets"] > 2000 and abs(r["pdus"] - r["packets"]) <= 10       # packets cut by the capture's end aside
-    assert r["design_a_identical"]
+    assert r["design_a_identical"] and r["sharded_identical"] and r["fallbacks"] == 0
     assert r["oracle_identical"], f"{r['oracle_pdus_differ']} PDUs differ from the oracle"
