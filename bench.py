@@ -141,6 +141,31 @@ def channeliser_leg(torch, g, dev, stream, total_bytes=1 << 30, reps=20):
     return res
 
 
+def block_leg(torch, g, dev, n_samples=1 << 23):
+    """Beside the headline (never part of `value`): the whole block -- GPU windows + the reference's state machine on the
+    host (lora_demod_core, demod_impl.cc:149-450) -- over a dense SF8 capture resident in HBM (the case of
+    tools/pipeline_bench.py without the channeliser): milliseconds and kernel launches per work() call."""
+    import time as _t
+    from importlib import import_module
+    synth = import_module("gr-lora_amd.synth")
+    cap = torch.from_numpy(synth.capture(8, n_samples, symbols_per_packet=64, seed=5)).to(dev)
+    blk = g.demod(8, False, BETA, 2, device=dev.index or 0)
+    best, pdus, st0 = None, 0, None
+    for _ in range(4):
+        blk.reset()
+        st0 = blk.stats
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        pdus = len(blk.work(cap))
+        dt = _t.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    st = blk.stats
+    blk.close()
+    return {"workload": f"SF8 F=2, {n_samples} samples in HBM, 64-symbol packets back to back", "pdus": pdus,
+            "calls": st["calls"], "launches": st["launches"], "on_demand": st["on_demand"], "rollbacks": st["rollbacks"],
+            "ms": round(best * 1e3, 3), "calls_per_s": round(st["calls"] / best, 0)}
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: this parent (which has not touched the GPU and never does) starts N rank
     processes of this file and relays their output; rank 0 prints the JSON line."""
@@ -331,6 +356,10 @@ def main():
                 line["next_rows"] = {"channeliser": channeliser_leg(torch, g, dev, stream)}
             except Exception as e:              # the headline line must not depend on this leg
                 line["next_rows"] = {"channeliser": {"error": str(e)[:200]}}
+            try:
+                line["next_rows"]["block"] = block_leg(torch, g, dev)
+            except Exception as e:
+                line["next_rows"]["block"] = {"error": str(e)[:200]}
         if cpu is not None:                              # reported at N=1 only; measured before the GPU was touched
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
