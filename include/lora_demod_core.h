@@ -98,7 +98,7 @@ LORA_HIP_API int lora_demod_core_preload(lora_demod_core_t *c, uint64_t start, s
  * the state machine to find the header/payload windows, evaluates those, and only then runs the state machine for
  * real -- a fixed number of launches whatever the number of packets; whatever the plan did not foresee is evaluated on
  * demand.  The PDUs and the trace are the same either way (a plan only chooses which windows are evaluated early).
- * mode 0: off (every window on demand, in speculative sweeps); 1 (default): inputs of at least 128 symbols;
+ * mode 0: off (every window on demand, in speculative sweeps); 1 (default): inputs of at least 1024 symbols;
  * 2: every input.  The environment variable LORA_CORE_PLAN sets the default of new blocks. */
 LORA_HIP_API int lora_demod_core_set_plan(lora_demod_core_t *c, int mode);
 /* plans started, READ stages redone after a surprise, windows that had to be evaluated on demand (each = one launch) */

@@ -129,10 +129,10 @@ def test_plan_uses_preloaded_lattice(g):
     """Results handed in through lora_demod_core_preload for all 16 phases replace the plan's own lattice sweep."""
     sf, f = 8, 2; n = 1 << sf; step = n // 16
     cap = dense_capture(sf, 20, seed=77, snr_db=10)
-    want, tr_w, st_w = run_block(g, sf, f, 0, [cap], plan=1)
+    want, tr_w, st_w = run_block(g, sf, f, 0, [cap], plan=2)
     framed = cases.gr_framed(cap, sf)
     h = g.capi.HipDemod(sf, f, cases.BETA)
-    blk = g.demod(sf, False, cases.BETA, f, plan=1)
+    blk = g.demod(sf, False, cases.BETA, f, plan=2)
     blk.enable_trace(1 << 17)
     for ph in range(16):
         cnt = (len(framed) - ph * step - n) // n + 1
@@ -156,7 +156,7 @@ def test_first_pass_misprediction_rolls_back(fault_at, g, monkeypatch):
     cap = dense_capture(sf, 30, seed=4242, snr_db=9)
     want, tr_w, _ = run_block(g, sf, f, 0, [cap], plan=0)
     monkeypatch.setenv("LORA_CORE_FAULT", str(fault_at))
-    got, tr_g, st = run_block(g, sf, f, 0, [cap], plan=1)
+    got, tr_g, st = run_block(g, sf, f, 0, [cap], plan=2)
     monkeypatch.delenv("LORA_CORE_FAULT")
     print(f"fault at prediction {fault_at}:", st)
     # (a fault that lands on a window that is squelched anyway, or behind the last S_RESET call, changes nothing)
