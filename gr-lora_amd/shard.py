@@ -107,6 +107,8 @@ def framed_slice(samples, sf, lo, hi):
     """Samples [lo, hi) of the framed stream = 3N-1 zeros (set_history(3N), lib/demod_impl.cc:103)
     followed by the capture."""
     hist = 3 * (1 << sf) - 1
+    if lo >= hist and hi - hist <= len(samples):          # wholly inside the capture: a view, nothing is copied
+        return samples[lo - hist:hi - hist]
     out = np.zeros(hi - lo, np.complex64)
     s_lo, s_hi = max(lo - hist, 0), min(hi - hist, len(samples))
     if s_hi > s_lo:
@@ -347,8 +349,13 @@ class BlockWalker:
         self.walks = 0
 
     def __call__(self, a, b):
-        self.blk.seek(a)
-        x = framed_slice(self.samples, self.sf, a, b)
+        hist = 3 * (1 << self.sf) - 1
+        if a == 0 and b > hist:            # the stream's true start: the block's own history zeros, no framed copy
+            self.blk.reset()
+            x = self.samples[:b - hist]
+        else:
+            self.blk.seek(a)
+            x = framed_slice(self.samples, self.sf, a, b)
         if self.on_device:
             import torch
             x = torch.from_numpy(x).cuda()
