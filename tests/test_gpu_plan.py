@@ -163,3 +163,36 @@ def test_first_pass_misprediction_rolls_back(fault_at, g, monkeypatch):
     assert st["rollbacks"] == 1 if fault_at < 400 else st["rollbacks"] <= 1
     assert same_pdus(want, got) and len(got) >= 20
     assert tr_w.tobytes() == tr_g.tobytes()
+
+
+def test_pinned_results_and_bins_only(g):
+    """LORA_HIP_OUT_PINNED (results straight into the caller's page-locked arrays) and LORA_HIP_NO_VAL (bins only) give the
+    same bits as the plain host-output call."""
+    import ctypes as C
+    capi = g.capi
+    L = capi.lib()
+    sf = 8; n = 1 << sf; count = 300
+    rng = np.random.default_rng(11)
+    iq = (rng.standard_normal(count * n + 5) + 1j * rng.standard_normal(count * n + 5)).astype(np.complex64)
+    h = capi.HipDemod(sf, 2, cases.BETA)
+    idx0, val0 = h.batch_strided(iq, 3, n, count, chirp_off=17)
+    pi, pv = C.c_void_p(), C.c_void_p()
+    assert L.lora_hip_host_alloc(C.byref(pi), count * 2) == 0 and L.lora_hip_host_alloc(C.byref(pv), count * 4) == 0
+    try:
+        idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint16)), (count,))
+        val = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_float)), (count,))
+        OUT_PINNED, NO_VAL = capi.OUT_PINNED, capi.NO_VAL
+        idx[:] = 0xFFFF; val[:] = -7
+        rc = L.lora_hip_demod_batch_strided(h._h, iq.ctypes.data, len(iq), 3, n, count, 17, 0, capi.WIN_UP, pi, pv, OUT_PINNED)
+        assert rc == 0 and np.array_equal(idx, idx0) and val.tobytes() == val0.tobytes()
+        idx[:] = 0xFFFF; val[:] = -7
+        rc = L.lora_hip_demod_batch_strided(h._h, iq.ctypes.data, len(iq), 3, n, count, 17, 0, capi.WIN_UP, pi, None, OUT_PINNED | NO_VAL)
+        assert rc == 0 and np.array_equal(idx, idx0) and np.all(val == -7)
+        plain = np.full(count, 0xFFFF, np.uint16)
+        rc = L.lora_hip_demod_batch_strided(h._h, iq.ctypes.data, len(iq), 3, n, count, 17, 0, capi.WIN_UP, plain.ctypes.data, None, NO_VAL)
+        assert rc == 0 and np.array_equal(plain, idx0)
+        # without the flag a missing value array is an error, as before
+        assert L.lora_hip_demod_batch_strided(h._h, iq.ctypes.data, len(iq), 3, n, count, 17, 0, capi.WIN_UP, plain.ctypes.data, None, 0) == capi.EINVAL
+    finally:
+        L.lora_hip_host_free(pi); L.lora_hip_host_free(pv)
+        h.close()
