@@ -334,7 +334,14 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
       h->tw_off[ps] = tw.size();
       const bool small = lora_hip::pass_table_in_lds((int)sf, (int)F, ps);
       for (unsigned rr = 0; rr < F; rr++) {
-        if (small) {          // float2 [F][r-1][NS]
+        if (small && LORA_POLY16 && sf == 12 && ps == 1) {
+          // SF12 pass 1 runs as Dft<16>::run_poly: rows 0..7 hold b^8, b^4, b^2, b^2*W8, b, b*W16, b*W16^2, b*W16^3 of the
+          // butterfly's base twiddle b = W_M^((N/L)*(F*jm + rr)); the other seven rows of the [r-1] layout are not read
+          const unsigned long long q = mt / 16;                 // W16 = W_M^(M/16)
+          const unsigned long long kk[15] = {8, 4, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, cc[15] = {0, 0, 0, 2, 0, 1, 2, 3, 0, 0, 0, 0, 0, 0, 0};
+          for (unsigned long long row = 0; row + 1 < r; row++)
+            for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(kk[row] * (n / L) * (F * jm + rr) + cc[row] * q));
+        } else if (small) {   // float2 [F][r-1][NS]
           for (unsigned long long mm = 1; mm < r; mm++)
             for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(mm * (n / L) * (F * jm + rr)));
         } else {              // float2 [F][NS]: the base twiddle of each butterfly only

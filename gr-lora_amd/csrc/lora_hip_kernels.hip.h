@@ -186,6 +186,13 @@ __device__ __forceinline__ void bfly_tw(const float2 p, const float2 w, const fl
   a1.x = __builtin_fmaf(2.0f, p.x, -a0.x);
   a1.y = __builtin_fmaf(2.0f, p.y, -a0.y);
 }
+// the same with the factor -j*w: -j*(w*b) swaps the components of w*b, which the FMAs absorb
+__device__ __forceinline__ void bfly_tw_mj(const float2 p, const float2 w, const float2 b, float2 &a0, float2 &a1) {
+  a0.x = __builtin_fmaf(w.y, b.x, __builtin_fmaf(w.x, b.y, p.x));
+  a0.y = __builtin_fmaf(w.y, b.y, __builtin_fmaf(-w.x, b.x, p.y));
+  a1.x = __builtin_fmaf(2.0f, p.x, -a0.x);
+  a1.y = __builtin_fmaf(2.0f, p.y, -a0.y);
+}
 // w = (1 - j)/sqrt2 (W8^1): w*b = ((b.x + b.y), (b.y - b.x)) / sqrt2
 __device__ __forceinline__ void bfly_w8_1(const float2 p, const float2 b, float2 &a0, float2 &a1) {
   const float t1 = b.x + b.y, t2 = b.y - b.x;
@@ -258,6 +265,47 @@ template <> struct Dft<16> {
   }
   __device__ static __forceinline__ void run(float2 *x) { run_impl<false>(x, nullptr); }
   __device__ static __forceinline__ void run_tw(float2 *x, const float2 *w) { run_impl<true>(x, w); }
+
+  // The same transform as run_tw with w[k] = w^k (pass twiddles are powers of one base per butterfly), from eight
+  // values instead of fifteen: y[j] = sum_k x[k] z_j^k with z_j = w * W16^j is the polynomial with coefficients x
+  // evaluated at sixteen points, and splitting it into even and odd coefficients four times (z_(j+8) = -z_j,
+  // z_j^2 = w^2 * W8^j, ...) leaves four levels of eight butterflies p +- t*q whose factors are w^8; w^4 and -j*w^4;
+  // w^2, w^2*W8 and -j times those; w*W16^j, j < 4, and -j times those.  -j costs nothing (operands swap), so
+  // t[8] = {w^8, w^4, w^2, w^2*W8, w, w*W16, w*W16^2, w*W16^3} is all it takes: 192 instructions (32 butterflies of
+  // 6) and no internal constants, against 194 plus 53 for forming fifteen powers.
+  __device__ static __forceinline__ void run_poly(float2 *x, const float2 (&t)[8]) {
+    float2 a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) bfly_tw(x[k], t[0], x[k + 8], a[k], b[k]);
+    float2 c[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      bfly_tw(a[k], t[1], a[k + 4], c[k][0], c[k][2]);
+      bfly_tw_mj(b[k], t[1], b[k + 4], c[k][1], c[k][3]);
+    }
+    float2 d[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      bfly_tw(c[k][0], t[2], c[k + 2][0], d[k][0], d[k][4]);
+      bfly_tw(c[k][1], t[3], c[k + 2][1], d[k][1], d[k][5]);
+      bfly_tw_mj(c[k][2], t[2], c[k + 2][2], d[k][2], d[k][6]);
+      bfly_tw_mj(c[k][3], t[3], c[k + 2][3], d[k][3], d[k][7]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bfly_tw(d[0][j], t[4 + j], d[1][j], x[j], x[j + 8]);
+      bfly_tw_mj(d[0][j + 4], t[4 + j], d[1][j + 4], x[j + 4], x[j + 12]);
+    }
+  }
+  // t[8] of run_poly from the base twiddle: three squarings and four products (25 instructions)
+  __device__ static __forceinline__ void poly_factors(const float2 w, float2 (&t)[8]) {
+    t[4] = w;
+    t[2] = csqr(w); t[1] = csqr(t[2]); t[0] = csqr(t[1]);
+    t[3] = make_float2((t[2].x + t[2].y) * LORA_SQRT1_2, (t[2].y - t[2].x) * LORA_SQRT1_2);       // * W8 = (1 - j)/sqrt2
+    t[5] = cmul(w, make_float2(LORA_COS_PI_8, -LORA_SIN_PI_8));                                   // * W16
+    t[6] = make_float2((w.x + w.y) * LORA_SQRT1_2, (w.y - w.x) * LORA_SQRT1_2);                   // * W16^2
+    t[7] = cmul(w, make_float2(LORA_SIN_PI_8, -LORA_COS_PI_8));                                   // * W16^3
+  }
 };
 
 // ---- geometry ---------------------------------------------------------------------------
@@ -315,6 +363,10 @@ constexpr unsigned kTicketQueues = 8, kWaveTicketQueues = 32, kTicketStride = 32
 #ifndef LORA_TWPRE
 #define LORA_TWPRE 1      // pass twiddles that live in LDS are requested before the pass's barrier (their latency hides behind
                           // the scatter drain and the barrier) instead of one by one between the multiplies
+#endif
+#ifndef LORA_POLY16
+#define LORA_POLY16 1     // SF12: the twiddled radix-16 passes run as Dft<16>::run_poly (eight factors per butterfly instead of
+                          // fifteen powers: 8 instead of 15 LDS reads in pass 1, 25 instead of 53 instructions of powers in pass 2)
 #endif
 #ifndef LORA_KTRACK
 #define LORA_KTRACK 0     // 1: the per-thread argmax scan tracks the register index only (fewer instructions, but measured
@@ -516,11 +568,12 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
   constexpr bool kTwPre12 = LORA_TWPRE && twpre_fits(12, F) && !(LORA_ABL & 32);
+  constexpr int NT1 = LORA_POLY16 ? 8 : 15;          // rows of the pass-1 table this kernel reads (the host fills them to match)
   float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
   if constexpr (kTwPre12) {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
-    for (int m = 1; m < 16; m++) t1[m - 1] = lds_read<lds_single(12)>(&tp[(m - 1) * 16]);
+    for (int m = 0; m < NT1; m++) t1[m] = lds_read<lds_single(12)>(&tp[m * 16]);
   }
   hook(1);
   LORA_STAMP(6);
@@ -538,10 +591,15 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     if constexpr (!kTwPre12) {
       const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
 #pragma unroll
-      for (int m = 1; m < 16; m++) t1[m - 1] = lds_read<lds_single(12)>(&tp[(m - 1) * 16]);
+      for (int m = 0; m < NT1; m++) t1[m] = lds_read<lds_single(12)>(&tp[m * 16]);
     }
     hook(2);
-    Dft<16>::run_tw(v, t1 - 1);                      // twiddles folded into the first butterflies; n1 -> kb
+    if constexpr (LORA_POLY16) {
+      const float2 (&t8)[8] = reinterpret_cast<const float2 (&)[8]>(t1);
+      Dft<16>::run_poly(v, t8);                      // n1 -> kb
+    } else {
+      Dft<16>::run_tw(v, t1 - 1);                    // twiddles folded into the first butterflies; n1 -> kb
+    }
   }
   LORA_FENCE1();
   LORA_FENCE1();
@@ -565,6 +623,12 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     float2 w[16];
     w[1] = w1_in;
     asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));     // loop-invariant, but 30 registers of hoisted powers would spill
+    if constexpr (LORA_POLY16) {
+      float2 t8[8];
+      Dft<16>::poly_factors(w[1], t8);
+      Dft<16>::run_poly(v, t8);                      // n0 -> kc: v[kc] is bin g + 256*kc
+      return;
+    }
     w[2] = csqr(w[1]); w[4] = csqr(w[2]); w[8] = csqr(w[4]);
     w[3] = cmul(w[1], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
 #pragma unroll

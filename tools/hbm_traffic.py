@@ -8,7 +8,7 @@ kernel = None
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = []
     for f in glob.glob(os.path.join(root, "gpurun_out", "pmc_hbm", c, "**", "*counter_collection.csv"), recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if "demod_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        rows += [r for r in csv.DictReader(open(f)) if "demod_kernel<12, 2, true" in r["Kernel_Name"] and r["Counter_Name"] == c]   # the headline kernel only
     per = [float(r["Counter_Value"]) for r in rows]
     vals[c] = sum(per) / len(per)
     kernel = rows[0]["Kernel_Name"]
