@@ -40,6 +40,7 @@ struct lora_hip_demod {
   // a call costs one device-to-host copy
   unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
   unsigned *d_ticket = nullptr;          // window-group ticket counter of the persistent kernel
+  bool ticket_dirty = false;             // the last launch failed: clear the counters before the next
   unsigned long long *d_dbg = nullptr;   // LORA_STAMPS builds only
   char hip_err[256] = {0};
   const char *kernel_name = "";
@@ -54,7 +55,7 @@ std::mutex g_scratch_mu;
 unsigned *g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU, by device index
 
 int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
-  if (h) snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e));
+  if (h) { snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e)); h->ticket_dirty = true; }
   return LORA_HIP_EHIP;
 }
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
@@ -187,12 +188,15 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   (void)hipMemsetAsync(h->d_dbg, 0, ndbg * sizeof(unsigned long long), h->stream);
   p.dbg = h->d_dbg;
 #endif
-  {
-    // the counters must start at zero: the array keeps the previous launch's values
+  // The counters must be zero at the launch.  They are when the buffer is new (create() clears the handle's own; the
+  // library's __device__ array starts as zeros) and after every launch that ran to its end: the kernel's last workgroup
+  // clears them.  A launch that failed leaves them undefined, so the next one clears them itself.
+  if (h->ticket_dirty) {
     hipError_t em = hipMemsetAsync(ticket, 0, kScratchWords * sizeof(unsigned), h->stream);
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
-    p.ticket = ticket;
+    h->ticket_dirty = false;
   }
+  p.ticket = ticket;
   p.twist = h->d_twist; p.fr = h->fft_factor;
   hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), lds, h->stream, p);
 #if LORA_STAMPS
@@ -216,7 +220,7 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   }
 #endif
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+  if (e != hipSuccess) { h->ticket_dirty = true; return hip_fail(h, e, "kernel launch"); }
   return LORA_HIP_OK;
 }
 
@@ -361,6 +365,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_win, n * sizeof(float)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_ticket, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMemset(h->d_ticket, 0, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);

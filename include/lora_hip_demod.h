@@ -158,8 +158,9 @@ LORA_HIP_API void lora_hip_host_free(void *p);
  * (4 KiB), lies in a file-scope __device__ array of the library instead of a buffer the handle allocated.
  *   - iq_dev, max_idx_dev and max_val_dev are device pointers on the handle's GPU; nothing is copied to or from
  *     the host and nothing is allocated or freed (no hipMalloc/hipFree/hipHostMalloc, no growth of staging buffers).
- *   - The call only enqueues a 4 KiB memset of the scratch and the kernel on the handle's stream
- *     (lora_hip_demod_set_stream); the caller synchronises.
+ *   - The call only enqueues the kernel on the handle's stream (lora_hip_demod_set_stream); the caller synchronises.
+ *     The counters are zero when the library is loaded and the kernel's last workgroup returns them to zero, so no
+ *     memset is enqueued (only after a HIP error on this handle does the next call clear them first).
  *   - count above LORA_HIP_NOALLOC_MAX_WINDOWS is refused with LORA_HIP_EINVAL (text in lora_hip_last_hip_error).
  *   - Every call on one GPU shares that GPU's scratch array, whatever the handle: calls that overlap in time on one
  *     GPU (different streams or threads) race on the counters.  Calls queued on one stream are safe.

@@ -60,6 +60,9 @@ if __name__ == "__main__":
         i = args.index("--reps"); reps = int(args[i + 1]); del args[i:i + 2]
     if "--settle" in args:
         i = args.index("--settle"); settle = float(args[i + 1]); del args[i:i + 2]
+    gib = 1.0
+    if "--gib" in args:
+        i = args.index("--gib"); gib = float(args[i + 1]); del args[i:i + 2]
     cfgs = [tuple(int(x) for x in a.split(",")) for a in args] or [(12, 2), (12, 1), (12, 4)]
-    good = all([run(sf, f, reps, settle) for sf, f in cfgs])
+    good = all([run(sf, f, reps, settle, int(gib * (1 << 30))) for sf, f in cfgs])
     sys.exit(0 if good else 1)
