@@ -334,6 +334,10 @@ def main():
                 secondary = {"bound": "valu_f32", "achieved": round(ach, 1), "peak": j["peak_spec_g_wave_instr_per_s"],
                              "unit": "G wave-instr/s", "frac": round(ach / j["peak_spec_g_wave_instr_per_s"], 4),
                              "wave_instr_per_symbol": j["valu_wave_instr_per_symbol"]}
+                if "lds_bytes_per_symbol" in j:      # the other secondary roof SURVEY 8d names: LDS bandwidth
+                    lds = j["lds_bytes_per_symbol"] * count / (kernel_ms * 1e-3) / 1e9
+                    secondary["lds"] = {"bound": "lds", "achieved": round(lds, 1), "peak": j["lds_peak_gbs"], "unit": "GB/s",
+                                        "frac": round(lds / j["lds_peak_gbs"], 4), "bytes_per_symbol": j["lds_bytes_per_symbol"]}
         line = {
             "metric": "demodulated symbols/sec (Msym/s) at SF12 fft_factor=2",
             "value": round(value, 3), "unit": "Msym/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
