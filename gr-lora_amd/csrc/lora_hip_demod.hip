@@ -338,11 +338,16 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
       h->tw_off[ps] = tw.size();
       const bool small = lora_hip::pass_table_in_lds((int)sf, (int)F, ps);
       for (unsigned rr = 0; rr < F; rr++) {
-        if (small && LORA_POLY16 && sf == 12 && ps == 1) {
-          // SF12 pass 1 runs as Dft<16>::run_poly: rows 0..7 hold b^8, b^4, b^2, b^2*W8, b, b*W16, b*W16^2, b*W16^3 of the
-          // butterfly's base twiddle b = W_M^((N/L)*(F*jm + rr)); the other seven rows of the [r-1] layout are not read
-          const unsigned long long q = mt / 16;                 // W16 = W_M^(M/16)
-          const unsigned long long kk[15] = {8, 4, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, cc[15] = {0, 0, 0, 2, 0, 1, 2, 3, 0, 0, 0, 0, 0, 0, 0};
+        const bool poly_gen = LORA_POLY16 && LORA_POLY_GEN && (r == 16 || r == 8);
+        if (small && LORA_POLY16 && ((sf == 12 && ps == 1) || poly_gen)) {
+          // twiddled radix-16 / radix-8 butterflies run as a polynomial evaluation (Dft<16>::run_poly, dft8_poly): the first
+          // r/2 rows hold the factors of the butterfly's base twiddle b = W_M^((N/L)*(F*jm + rr)) --
+          //   r = 16: b^8, b^4, b^2, b^2*W8, b, b*W16, b*W16^2, b*W16^3        r = 8: b^4, b^2, b, b*W8
+          // -- and the other rows of the [r-1] layout are not read
+          const unsigned long long q = mt / r;                  // W_r = W_M^(M/r)
+          const unsigned long long kk16[15] = {8, 4, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, cc16[15] = {0, 0, 0, 2, 0, 1, 2, 3, 0, 0, 0, 0, 0, 0, 0};
+          const unsigned long long kk8[7] = {4, 2, 1, 1, 0, 0, 0}, cc8[7] = {0, 0, 0, 1, 0, 0, 0};
+          const unsigned long long *kk = r == 16 ? kk16 : kk8, *cc = r == 16 ? cc16 : cc8;
           for (unsigned long long row = 0; row + 1 < r; row++)
             for (unsigned long long jm = 0; jm < NS; jm++) tw.push_back(wm(kk[row] * (n / L) * (F * jm + rr) + cc[row] * q));
         } else if (small) {   // float2 [F][r-1][NS]

@@ -193,6 +193,28 @@ __device__ __forceinline__ void bfly_tw_mj(const float2 p, const float2 w, const
   a1.x = __builtin_fmaf(2.0f, p.x, -a0.x);
   a1.y = __builtin_fmaf(2.0f, p.y, -a0.y);
 }
+// Twiddled DFT8 as a polynomial evaluation (see Dft<16>::run_poly): y[j] = sum_k x[k] (w*W8^j)^k from the four factors
+// t = {w^4, w^2, w, w*W8}: three levels of four butterflies, 72 instructions, against 28 for seven products and 56 for the DFT8
+__device__ __forceinline__ void dft8_poly(float2 *x, const float2 (&t)[4]) {
+  float2 a[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) bfly_tw(x[k], t[0], x[k + 4], a[k], b[k]);
+  float2 c[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    bfly_tw(a[k], t[1], a[k + 2], c[k][0], c[k][2]);
+    bfly_tw_mj(b[k], t[1], b[k + 2], c[k][1], c[k][3]);
+  }
+  bfly_tw(c[0][0], t[2], c[1][0], x[0], x[4]);
+  bfly_tw(c[0][1], t[3], c[1][1], x[1], x[5]);
+  bfly_tw_mj(c[0][2], t[2], c[1][2], x[2], x[6]);
+  bfly_tw_mj(c[0][3], t[3], c[1][3], x[3], x[7]);
+}
+__device__ __forceinline__ void dft8_poly_factors(const float2 w, float2 (&t)[4]) {
+  t[2] = w;
+  t[1] = csqr(w); t[0] = csqr(t[1]);
+  t[3] = make_float2((w.x + w.y) * LORA_SQRT1_2, (w.y - w.x) * LORA_SQRT1_2);                     // * W8 = (1 - j)/sqrt2
+}
 // w = (1 - j)/sqrt2 (W8^1): w*b = ((b.x + b.y), (b.y - b.x)) / sqrt2
 __device__ __forceinline__ void bfly_w8_1(const float2 p, const float2 b, float2 &a0, float2 &a1) {
   const float t1 = b.x + b.y, t2 = b.y - b.x;
@@ -369,6 +391,9 @@ constexpr unsigned kTicketDoneWord = 16;      // workgroups that have finished d
 #define LORA_POLY16 1     // SF12: the twiddled radix-16 passes run as Dft<16>::run_poly (eight factors per butterfly instead of
                           // fifteen powers: 8 instead of 15 LDS reads in pass 1, 25 instead of 53 instructions of powers in pass 2)
 #endif
+#ifndef LORA_POLY_GEN
+#define LORA_POLY_GEN 1   // the generic passes' twiddled radix-16 and radix-8 butterflies in the same form (tables hold 8 / 4 factors)
+#endif
 #ifndef LORA_KTRACK
 #define LORA_KTRACK 0     // 1: the per-thread argmax scan tracks the register index only (fewer instructions, but measured
                           // neutral, and the allocator spills in several variants)
@@ -457,13 +482,16 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
   static_assert(NS % 16 == 0 || NS == 8 || NS == 1, "pad split: o + m*NS must not carry out of bit 3");
   LORA_STAMP(2);                     // compute (butterflies, scatter) since the last stamp
   constexpr bool kTwPre = LORA_TWPRE && twpre_fits(LOGN, F) && PS > 0 && pass_table_in_lds(LOGN, F, PS);
-  float2 tpre[kTwPre ? nb * (r - 1) : 1];
+  // polynomial form (Dft<16>::run_poly, dft8_poly): the table's first NF rows hold the butterfly's factors (host: create())
+  constexpr bool kPoly = LORA_POLY16 && LORA_POLY_GEN && PS > 0 && (r == 16 || r == 8);
+  constexpr int NF = kPoly ? r / 2 : r - 1;
+  float2 tpre[kTwPre ? nb * NF : 1];
   if constexpr (kTwPre) {            // this pass's twiddles (read-only LDS table): requested before the barrier
 #pragma unroll
     for (int q = 0; q < nb; q++) {
       const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + ((tw + q * T) & (NS - 1));
 #pragma unroll
-      for (int m = 1; m < r; m++) tpre[q * (r - 1) + m - 1] = lds_read<lds_single(LOGN)>(&tp[(m - 1) * NS]);
+      for (int e = 0; e < NF; e++) tpre[q * NF + e] = lds_read<lds_single(LOGN)>(&tp[e * NS]);
     }
   }
   if constexpr (PS > 0) {
@@ -486,11 +514,27 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
     for (int m = 0; m < r; m++) a[m] = v[q + m * nb];
     if constexpr (PS > 0) {
       const int jm = j & (NS - 1);
-      float2 w[r];                   // w[m], m >= 1: this butterfly's pass twiddles
-#if LORA_ABL & 4
+      if constexpr (kPoly) {
+        float2 t[NF];                // the butterfly's factors
+        if constexpr (kTwPre) {
 #pragma unroll
-      for (int m = 1; m < r; m++) w[m] = make_float2(0.6f + m, 0.8f);
-#else
+          for (int e = 0; e < NF; e++) t[e] = tpre[q * NF + e];
+        } else if constexpr (pass_table_in_lds(LOGN, F, PS)) {
+          const float2 *tp = lds_tw + pass_lds_offset(LOGN, F, PS) + (rr * (r - 1)) * NS + jm;
+#pragma unroll
+          for (int e = 0; e < NF; e++) t[e] = lds_read<lds_single(LOGN)>(&tp[e * NS]);
+        } else {
+          // base twiddle of this butterfly from the caller's registers; the other factors are products
+          static_assert(last, "only the last pass has a table too big for LDS");
+          float2 w1 = wb[q];
+          asm volatile("" : "+v"(w1.x), "+v"(w1.y));     // loop-invariant, but hoisted factors would cost r registers
+          if constexpr (r == 16) Dft<16>::poly_factors(w1, t);
+          else dft8_poly_factors(w1, t);
+        }
+        if constexpr (r == 16) Dft<16>::run_poly(a, t);
+        else dft8_poly(a, t);
+      } else {
+      float2 w[r];                   // w[m], m >= 1: this butterfly's pass twiddles
       if constexpr (kTwPre) {
 #pragma unroll
         for (int m = 1; m < r; m++) w[m] = tpre[q * (r - 1) + m - 1];
@@ -512,13 +556,13 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
           for (int m = 1; m < 8; m++) w[8 + m] = cmul(w[8], w[m]);
         }
       }
-#endif
       if constexpr (r == 16) {
         Dft<16>::run_tw(a, w);       // twiddles folded into the first butterflies
       } else {
 #pragma unroll
         for (int m = 1; m < r; m++) a[m] = cmul(a[m], w[m]);
         Dft<r>::run(a);
+      }
       }
     } else {
       Dft<r>::run(a);
