@@ -132,6 +132,8 @@ __device__ __forceinline__ float2 mul_w64(float2 a, int k) {
   const float c = cos64(k), sn = -cos64(k - 16);  // W = c + j*sn, sn = -sin(2 pi k / 64)
   return make_float2(__builtin_fmaf(a.x, c, -(a.y * sn)), __builtin_fmaf(a.x, sn, a.y * c));
 }
+// W_64^k itself (folds to literals like the above)
+__device__ __forceinline__ float2 w64c(int k) { return make_float2(cos64(k & 63), -cos64((k - 16) & 63)); }
 __device__ __forceinline__ float2 csqr(float2 a) {
   const float ab = a.x * a.y;
   return make_float2(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), ab + ab);
@@ -214,6 +216,17 @@ __device__ __forceinline__ void dft8_poly_factors(const float2 w, float2 (&t)[4]
   t[2] = w;
   t[1] = csqr(w); t[0] = csqr(t[1]);
   t[3] = make_float2((w.x + w.y) * LORA_SQRT1_2, (w.y - w.x) * LORA_SQRT1_2);                     // * W8 = (1 - j)/sqrt2
+}
+#ifndef LORA_POLY_TWIST
+#define LORA_POLY_TWIST 0   // 1: pass 0 of sub-transform rr >= 1 -- the zero-padding twist W_(F*R)^(rr*k) on input k is a power of
+                            // one constant -- runs as one polynomial-form transform with literal factors (192 / 72
+                            // instructions) instead of up to 15 / 7 constant multiplies in front of the plain DFT.
+                            // Measured 0.5-1.5 % slower at every SF and F (the plain DFT's internal constants are
+                            // cheaper than general factors, and several twist constants are trivial): off
+#endif
+// factors of the base W_64^s for dft8_poly: {c^4, c^2, c, c*W8}
+__device__ __forceinline__ void twist_factors8(const int s, float2 (&t)[4]) {
+  t[0] = w64c(4 * s); t[1] = w64c(2 * s); t[2] = w64c(s); t[3] = w64c(s + 8);
 }
 // w = (1 - j)/sqrt2 (W8^1): w*b = ((b.x + b.y), (b.y - b.x)) / sqrt2
 __device__ __forceinline__ void bfly_w8_1(const float2 p, const float2 b, float2 &a0, float2 &a1) {
@@ -327,6 +340,11 @@ template <> struct Dft<16> {
     t[5] = cmul(w, make_float2(LORA_COS_PI_8, -LORA_SIN_PI_8));                                   // * W16
     t[6] = make_float2((w.x + w.y) * LORA_SQRT1_2, (w.y - w.x) * LORA_SQRT1_2);                   // * W16^2
     t[7] = cmul(w, make_float2(LORA_SIN_PI_8, -LORA_COS_PI_8));                                   // * W16^3
+  }
+  // the same for the constant base W_64^s (pass-0 twist): literals
+  __device__ static __forceinline__ void twist_factors(const int s, float2 (&t)[8]) {
+    t[0] = w64c(8 * s); t[1] = w64c(4 * s); t[2] = w64c(2 * s); t[3] = w64c(2 * s + 8);
+    t[4] = w64c(s); t[5] = w64c(s + 4); t[6] = w64c(s + 8); t[7] = w64c(s + 12);
   }
 };
 
@@ -565,7 +583,18 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[plan_points(LOGN)], float2 
       }
       }
     } else {
-      Dft<r>::run(a);
+      if constexpr (LORA_POLY16 && LORA_POLY_GEN && LORA_POLY_TWIST && (r == 16 || r == 8) && 64 % (F * r) == 0) {
+        // pass 0: the caller left the zero-padding twist W_(F*R)^(rr*k) of sub-transform rr to this transform
+        if (rr > 0) {
+          const int s64 = rr * (64 / (F * r));
+          if constexpr (r == 16) { float2 t[8]; Dft<16>::twist_factors(s64, t); Dft<16>::run_poly(a, t); }
+          else { float2 t[4]; twist_factors8(s64, t); dft8_poly(a, t); }
+        } else {
+          Dft<r>::run(a);
+        }
+      } else {
+        Dft<r>::run(a);
+      }
     }
     if constexpr (!last) {
       const int o = (j / NS) * NS * r + (j & (NS - 1));
@@ -602,7 +631,13 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   static_assert(pass_table_in_lds(12, F, 1) && !pass_table_in_lds(12, F, 2), "table placement assumed below");
   constexpr int ROW = 272;
   const int hi = tw >> 4, lo = tw & 15;
-  Dft<16>::run(v);                                   // n2 -> ka
+  if (LORA_POLY16 && LORA_POLY_GEN && LORA_POLY_TWIST && rr > 0) {   // twist of sub-transform rr and DFT in one (see fft_pass)
+    float2 t[8];
+    Dft<16>::twist_factors(rr * (64 / (F * 16)), t);
+    Dft<16>::run_poly(v, t);                         // n2 -> ka
+  } else {
+    Dft<16>::run(v);                                 // n2 -> ka
+  }
 #if !(LORA_ABL & 32)
   LORA_STAMP(2);
   if (!(LORA_ABL & 128)) __syncthreads();            // every wave is done with the previous transform's rows
@@ -990,6 +1025,10 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
         const float2 *__restrict__ tws = p.twist + rr * tw;         // W_M^(rr*(tw + k*T))
 #pragma unroll
         for (int k = 0; k < R; k++) v[k] = cmul(x[k], tws[k * (rr * T)]);
+      } else if constexpr (LORA_POLY16 && LORA_POLY_GEN && LORA_POLY_TWIST && (R == 16 || R == 8)) {
+        static_assert(64 % (F * R) == 0, "pass-0 twist constants are 64th roots of unity");
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = x[k];     // the twist W_M^(rr*k*T) is applied inside pass 0 (polynomial form)
       } else {
         static_assert(64 % (F * R) == 0, "pass-0 twist constants are 64th roots of unity");
 #pragma unroll
