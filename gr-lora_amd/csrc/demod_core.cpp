@@ -531,6 +531,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
     }
   } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   c->shadow = false; c->deferred = false;
+  const double t_walked = now_s();
   auto to_start = [&]() {
     static_cast<WalkState &>(*c) = saved; c->n_calls = saved_calls;
     while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
@@ -594,6 +595,8 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
   P.rd_cur = 0;
   c->t_stage[3] += t3 - t2; c->t_cb += now_s() - t3;
+  if (c->timing) fprintf(stderr, "[core]   first pass: state machine %.3f ms (%llu calls) | run list %.3f | check + fill in %.3f (%zu predicted calls)\n",
+                         (t_walked - t0) * 1e3, (unsigned long long)(c->n_calls - saved_calls), (t1 - t_walked) * 1e3, (t3 - t2) * 1e3, c->patches.size());
   return LORA_HIP_OK;
 }
 
