@@ -648,12 +648,18 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
   constexpr bool kTwPre12 = LORA_TWPRE && twpre_fits(12, F) && !(LORA_ABL & 32);
+#ifndef LORA_P1_BASE
+#define LORA_P1_BASE 0     // 1: pass 1 reads only its base twiddle from LDS and forms the other seven factors (25 instructions)
+#endif
   constexpr int NT1 = LORA_POLY16 ? 8 : 15;          // rows of the pass-1 table this kernel reads (the host fills them to match)
   float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
   if constexpr (kTwPre12) {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
+    if constexpr (LORA_P1_BASE && LORA_POLY16) t1[4] = lds_read<lds_single(12)>(&tp[4 * 16]);
+    else {
 #pragma unroll
-    for (int m = 0; m < NT1; m++) t1[m] = lds_read<lds_single(12)>(&tp[m * 16]);
+      for (int m = 0; m < NT1; m++) t1[m] = lds_read<lds_single(12)>(&tp[m * 16]);
+    }
   }
   hook(1);
   LORA_STAMP(6);
@@ -674,7 +680,11 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
       for (int m = 0; m < NT1; m++) t1[m] = lds_read<lds_single(12)>(&tp[m * 16]);
     }
     hook(2);
-    if constexpr (LORA_POLY16) {
+    if constexpr (LORA_POLY16 && LORA_P1_BASE) {
+      float2 t8[8];
+      Dft<16>::poly_factors(t1[4], t8);
+      Dft<16>::run_poly(v, t8);
+    } else if constexpr (LORA_POLY16) {
       const float2 (&t8)[8] = reinterpret_cast<const float2 (&)[8]>(t1);
       Dft<16>::run_poly(v, t8);                      // n1 -> kb
     } else {
