@@ -59,6 +59,8 @@ def cpu_baseline(capture, budget_s=12.0):
     sec, calls, ffts, pdus = oracle.time_stream(SF, False, BETA, FFT_FACTOR, capture, reps=reps)
     out = {
         "value": round(ffts * reps / sec / 1e6, 6), "unit": "Msym/s", "cores": 1, "kind": "port",
+        "unit_note": "counts FFT windows (every up-path window and every one of the 16 SFD windows of a sync call), the same unit as "
+                     "the GPU's stride-N windows; general_work calls alone are the `calls` figure in `sample`",
         "sample": (f"oracle general_work loop (3 allocs/call, dead multiply, memset+memcpy, full 8192-pt radix-2 FFT, "
                    f"scalar argmax; own FFT, not FFTW/VOLK) over the same 1.25 M-sample SF12 capture x {reps} passes: "
                    f"{calls} calls / {ffts} FFT windows / {pdus} PDUs per pass, {sec:.1f} s; "
@@ -109,6 +111,14 @@ def cpu_baseline(capture, budget_s=12.0):
     except Exception as e:                      # the single-core figure is the contract; this one is extra
         out["all_cores"] = {"error": str(e)[:200]}
     return out
+
+
+def kernel_header_sha256():
+    """SHA-256 of the device code the counter files under profiles/ were measured on (tools/hbm_traffic.py and
+    tools/valu_count.py store it): a counter figure is only passed on when the kernel source is still that one."""
+    import hashlib
+    with open(os.path.join(ROOT, "gr-lora_amd", "csrc", "lora_hip_kernels.hip.h"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def channeliser_leg(torch, g, dev, stream, total_bytes=1 << 30, reps=20):
@@ -316,24 +326,46 @@ def main():
         value = world * count * args.steps / elapsed / 1e6
         bytes_per_sym = 8 * n + 8                                  # IQ read once + (idx,val) written
         achieved = count * bytes_per_sym / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # Counter figures are NOT measured in this run: they come from rocprofv3 --pmc passes recorded under profiles/
+        # (a counter pass cannot run inside a timed bench).  Each file names the SHA-256 of the kernel source it was
+        # measured on; when the source in this tree is another one, the figure is withheld (null) and the source field says so.
+        sha = kernel_header_sha256()
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 j = json.load(f)
-            if j.get("kernel") == h.kernel_name and j.get("windows_per_launch") == count:
+            same = j.get("kernel_header_sha256") == sha
+            traffic_source = {"file": "profiles/hbm_traffic.json", "measured_in_this_run": False,
+                              "kernel_header_sha256": j.get("kernel_header_sha256"), "matches_current_source": same}
+            if same and j.get("kernel") == h.kernel_name and j.get("windows_per_launch") == count:
                 traffic = j.get("hbm_bytes_per_launch")
         secondary = None
         vc = os.path.join(ROOT, "profiles", "valu_count.json")
         if os.path.exists(vc):
             with open(vc) as f:
                 j = json.load(f)
-            if j.get("kernel") == h.kernel_name:
+            same = j.get("kernel_header_sha256") == sha
+            if j.get("kernel") == h.kernel_name and not same:
+                secondary = {"bound": "valu_f32", "achieved": None,
+                             "source": {"file": "profiles/valu_count.json", "measured_in_this_run": False,
+                                        "kernel_header_sha256": j.get("kernel_header_sha256"), "matches_current_source": False}}
+            if j.get("kernel") == h.kernel_name and same:
                 # the roof that actually binds at SF12 F=2 (SURVEY 8d asks for it beside the HBM one)
                 ach = j["valu_wave_instr_per_symbol"] * count / (kernel_ms * 1e-3) / 1e9
                 secondary = {"bound": "valu_f32", "achieved": round(ach, 1), "peak": j["peak_spec_g_wave_instr_per_s"],
                              "unit": "G wave-instr/s", "frac": round(ach / j["peak_spec_g_wave_instr_per_s"], 4),
-                             "wave_instr_per_symbol": j["valu_wave_instr_per_symbol"]}
+                             "wave_instr_per_symbol": j["valu_wave_instr_per_symbol"],
+                             "source": {"file": "profiles/valu_count.json", "measured_in_this_run": False,
+                                        "kernel_header_sha256": j.get("kernel_header_sha256"), "matches_current_source": True}}
+                if "valu_only_ms_per_launch" in j:   # the same kernel with its loads and LDS exchanges compiled out (LORA_ABL=33):
+                    # what a perfectly hidden memory system would leave -- the distance to the compute bound
+                    ceil_gbs = j["valu_only_windows_per_launch"] * bytes_per_sym / (j["valu_only_ms_per_launch"] * 1e-3) / 1e9
+                    secondary["valu_only_ceiling"] = {"frac_of_hbm_roofline": round(ceil_gbs / HBM_PEAK_GBS, 4),
+                                                      "ms_per_launch": j["valu_only_ms_per_launch"],
+                                                      "windows_per_launch": j["valu_only_windows_per_launch"],
+                                                      "this_run_frac_of_ceiling": round(achieved / ceil_gbs, 4),
+                                                      "note": j.get("valu_only_note")}
                 if "lds_bytes_per_symbol" in j:      # the other secondary roof SURVEY 8d names: LDS bandwidth
                     lds = j["lds_bytes_per_symbol"] * count / (kernel_ms * 1e-3) / 1e9
                     secondary["lds"] = {"bound": "lds", "achieved": round(lds, 1), "peak": j["lds_peak_gbs"], "unit": "GB/s",
@@ -349,7 +381,8 @@ def main():
                                    f"({n_samples * 8 / 2**30:.2f} GiB), {count} stride-N symbol windows per step per GPU",
                        "kernel": h.kernel_name, "parallelism": f"independent captures per GPU x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "valu_only_ceiling": (secondary or {}).get("valu_only_ceiling", {}).get("frac_of_hbm_roofline"),
                          "kernel_ms": round(kernel_ms, 4), "bytes_per_symbol": bytes_per_sym,
                          "symbols_per_launch": count,
                          "device_copy_gbs": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),

@@ -249,8 +249,11 @@ __device__ __forceinline__ void dft4_tail(const float2 a0, const float2 a1, cons
 template <> struct Dft<16> {
   // TW: inputs 1..15 are first multiplied by w[1..15] (the pass twiddles); folded into the first butterflies
   // 150 instructions untwiddled, 194 with the 15 twiddles (164 and 224 with separate multiplies)
-  template <bool TW>
-  __device__ static __forceinline__ void run_impl(float2 *x, const float2 *w) {
+  // out(k1), k1 < 4: called as soon as outputs k1, k1 + 4, k1 + 8, k1 + 12 are final (the caller may store them right there, so
+  // that its sixteen stores go out between the last butterflies instead of in one burst behind them)
+  struct NoOut { __device__ __forceinline__ void operator()(int) const {} };
+  template <bool TW, typename Out = NoOut>
+  __device__ static __forceinline__ void run_impl(float2 *x, const float2 *w, const Out &out = Out()) {
     // 4x4: u[c][k1] = DFT4 over m of x[c + 4m]
     float2 u[4][4];
 #pragma unroll
@@ -274,6 +277,7 @@ template <> struct Dft<16> {
     {
       dft4(u[0][0], u[1][0], u[2][0], u[3][0]);
       x[0] = u[0][0]; x[4] = u[1][0]; x[8] = u[2][0]; x[12] = u[3][0];
+      out(0);
     }
     {   // k1 = 1: W^1, W^2 = (1-j)/sqrt2, W^3
       float2 a0, a1, a2, a3;
@@ -281,6 +285,7 @@ template <> struct Dft<16> {
       bfly_w8_1(u[0][1], u[2][1], a0, a1);
       bfly_tw(p1, w3, u[3][1], a2, a3);
       dft4_tail(a0, a1, a2, a3, x[1], x[5], x[9], x[13]);
+      out(1);
     }
     {   // k1 = 2: W^2 = (1-j)/sqrt2, W^4 = -j, W^6 = (-1-j)/sqrt2
       float2 a0, a1, a2, a3;
@@ -289,6 +294,7 @@ template <> struct Dft<16> {
       a0 = cadd(u[0][2], b2); a1 = csub(u[0][2], b2);
       bfly_w8_3(p1, u[3][2], a2, a3);
       dft4_tail(a0, a1, a2, a3, x[2], x[6], x[10], x[14]);
+      out(2);
     }
     {   // k1 = 3: W^3, W^6 = (-1-j)/sqrt2, W^9
       float2 a0, a1, a2, a3;
@@ -296,9 +302,12 @@ template <> struct Dft<16> {
       bfly_w8_3(u[0][3], u[2][3], a0, a1);
       bfly_tw(p1, w9, u[3][3], a2, a3);
       dft4_tail(a0, a1, a2, a3, x[3], x[7], x[11], x[15]);
+      out(3);
     }
   }
   __device__ static __forceinline__ void run(float2 *x) { run_impl<false>(x, nullptr); }
+  template <typename Out>
+  __device__ static __forceinline__ void run_out(float2 *x, const Out &out) { run_impl<false, Out>(x, nullptr, out); }
   __device__ static __forceinline__ void run_tw(float2 *x, const float2 *w) { run_impl<true>(x, w); }
 
   // The same transform as run_tw with w[k] = w^k (pass twiddles are powers of one base per butterfly), from eight
@@ -308,7 +317,8 @@ template <> struct Dft<16> {
   // w^2, w^2*W8 and -j times those; w*W16^j, j < 4, and -j times those.  -j costs nothing (operands swap), so
   // t[8] = {w^8, w^4, w^2, w^2*W8, w, w*W16, w*W16^2, w*W16^3} is all it takes: 192 instructions (32 butterflies of
   // 6) and no internal constants, against 194 plus 53 for forming fifteen powers.
-  __device__ static __forceinline__ void run_poly(float2 *x, const float2 (&t)[8]) {
+  template <typename Out = NoOut>
+  __device__ static __forceinline__ void run_poly(float2 *x, const float2 (&t)[8], const Out &out = Out()) {
     float2 a[8], b[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) bfly_tw(x[k], t[0], x[k + 8], a[k], b[k]);
@@ -330,6 +340,7 @@ template <> struct Dft<16> {
     for (int j = 0; j < 4; j++) {
       bfly_tw(d[0][j], t[4 + j], d[1][j], x[j], x[j + 8]);
       bfly_tw_mj(d[0][j + 4], t[4 + j], d[1][j + 4], x[j + 4], x[j + 12]);
+      out(j);
     }
   }
   // t[8] of run_poly from the base twiddle: three squarings and four products (25 instructions)
@@ -428,6 +439,24 @@ constexpr unsigned kTicketDoneWord = 16;      // workgroups that have finished d
 #ifndef LORA_MIN_WAVES
 #define LORA_MIN_WAVES 3
 #endif
+// Round-3 co-issue experiments on the SF12 kernel (profiles/r03_kernel_experiments.md); all off in the product build.
+#ifndef LORA_PRIO
+#define LORA_PRIO 0       // wave priority (s_setprio).  1: static, by the wave's slot on its SIMD (HW_ID.wave_id): older slots higher;
+                          // 2: static, younger slots higher; 3: raised from the end of an LDS gather to the end of the butterfly
+                          // block and scatter that follow; 4: raised only while a wave issues its LDS scatter and gather
+#endif
+#ifndef LORA_STAGGER
+#define LORA_STAGGER 0    // 1: a workgroup delays its first window by (wave slot mod 3) thirds of a window period (s_sleep), so
+                          // that the three waves of a SIMD do not start in phase
+#endif
+#ifndef LORA_EARLY_BARRIER
+#define LORA_EARLY_BARRIER 0   // SF12: the barrier that protects a transform's rows from the next transform's scatter sits right behind
+                               // the wave-local exchange (its reads have landed) instead of in front of the scatter, so that the
+                               // scatter's stores can go out between the last butterflies of pass 0 instead of in one burst
+#endif
+#define LORA_PRIO_PHASE(on_butterflies) do { \
+    if (LORA_PRIO == 3) __builtin_amdgcn_s_setprio((on_butterflies) ? 1 : 0); \
+    else if (LORA_PRIO == 4) __builtin_amdgcn_s_setprio((on_butterflies) ? 0 : 1); } while (0)
 // Waves per SIMD the register budget is cut for.  SF9 keeps 8 points per thread (72-127 VGPRs), so it can run
 // six (F <= 2) or four (F = 4) instead of three: measured +17 % at F = 2, nothing at F = 1 (memory-bound).
 constexpr int min_waves(int logn, int f) {
@@ -635,14 +664,24 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     float2 t[8];
     Dft<16>::twist_factors(rr * (64 / (F * 16)), t);
     Dft<16>::run_poly(v, t);                         // n2 -> ka
+  } else if (LORA_EARLY_BARRIER >= 2 && !(LORA_ABL & 32)) {
+    // the scatter of exchange 1 (no barrier in front of it any more) rides on the last butterflies
+    float2 *o = tile + tw;
+    Dft<16>::run_out(v, [&](const int k1) {
+      LORA_SCHED_FENCE();
+#pragma unroll
+      for (int m = k1; m < 16; m += 4) o[m * ROW] = v[m];
+      LORA_SCHED_FENCE();
+    });
   } else {
     Dft<16>::run(v);                                 // n2 -> ka
   }
 #if !(LORA_ABL & 32)
   LORA_STAMP(2);
-  if (!(LORA_ABL & 128)) __syncthreads();            // every wave is done with the previous transform's rows
+  if (!(LORA_ABL & 128) && !LORA_EARLY_BARRIER) __syncthreads();   // every wave is done with the previous transform's rows
   LORA_STAMP(5);
-  {
+  LORA_PRIO_PHASE(false);
+  if (LORA_EARLY_BARRIER < 2) {
     float2 *o = tile + tw;
 #pragma unroll
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
@@ -670,6 +709,7 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = lds_read<lds_single(12)>(&i[m * 16]);   // thread (ka = hi, n0 = lo), register n1 = m
   }
+  LORA_PRIO_PHASE(true);
   LORA_STAMP(6);
 #endif
   LORA_FENCE1();
@@ -684,6 +724,15 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
       float2 t8[8];
       Dft<16>::poly_factors(t1[4], t8);
       Dft<16>::run_poly(v, t8);
+    } else if constexpr (LORA_POLY16 && LORA_EARLY_BARRIER >= 3 && !(LORA_ABL & (32 | 256))) {
+      const float2 (&t8)[8] = reinterpret_cast<const float2 (&)[8]>(t1);
+      float2 *o = tile + hi * ROW + lo;              // exchange 2's stores ride on the last butterflies
+      Dft<16>::run_poly(v, t8, [&](const int j) {
+        LORA_SCHED_FENCE();
+#pragma unroll
+        for (int m = j; m < 16; m += 4) o[m * 17] = v[m];
+        LORA_SCHED_FENCE();
+      });
     } else if constexpr (LORA_POLY16) {
       const float2 (&t8)[8] = reinterpret_cast<const float2 (&)[8]>(t1);
       Dft<16>::run_poly(v, t8);                      // n1 -> kb
@@ -695,14 +744,18 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   LORA_FENCE1();
   LORA_STAMP(2);
 #if !(LORA_ABL & (32 | 256))
+  LORA_PRIO_PHASE(false);
   {
     float2 *o = tile + hi * ROW + lo;
+    if (!(LORA_POLY16 && LORA_EARLY_BARRIER >= 3)) {
 #pragma unroll
-    for (int m = 0; m < 16; m++) o[m * 17] = v[m];   // own row: [kb = m][n0 = lo], wave-local
+      for (int m = 0; m < 16; m++) o[m * 17] = v[m];   // own row: [kb = m][n0 = lo], wave-local
+    }
     const float2 *i = tile + hi * ROW + lo * 17;
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = lds_read<lds_single(12)>(&i[m]);        // thread (ka = hi, kb = lo), register n0 = m
   }
+  LORA_PRIO_PHASE(true);
   LORA_STAMP(6);
 #endif
   hook(3);
@@ -716,6 +769,9 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
     if constexpr (LORA_POLY16) {
       float2 t8[8];
       Dft<16>::poly_factors(w[1], t8);
+#if LORA_EARLY_BARRIER && !(LORA_ABL & (32 | 128 | 256))
+      __syncthreads();                               // every wave has read its rows: the next transform may scatter at once
+#endif
       Dft<16>::run_poly(v, t8);                      // n0 -> kc: v[kc] is bin g + 256*kc
       return;
     }
@@ -913,6 +969,27 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
     }
   }
   __syncthreads();                 // the LDS twiddle tables and the ring are visible
+#if LORA_PRIO == 1 || LORA_PRIO == 2 || LORA_PRIO == 5 || LORA_PRIO == 6 || LORA_STAGGER
+  if constexpr (LOGN == 12) {
+    // HW_REG_HW_ID (id 4), bits 3:0: the wave's slot on its SIMD; three resident workgroups per CU fill slots in dispatch order.
+    // LORA_PRIO 5 / 6: the workgroup's rank in the grid instead (blockIdx.x / (gridDim.x / 3)): the same for its four waves
+#if LORA_PRIO == 5 || LORA_PRIO == 6 || LORA_STAGGER == 2
+    const unsigned slot = (blockIdx.x / (gridDim.x / 3u)) % 3u;
+#else
+    const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) % 3u;
+#endif
+#if LORA_PRIO == 1 || LORA_PRIO == 5
+    if (slot == 0) __builtin_amdgcn_s_setprio(2); else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+#elif LORA_PRIO == 2 || LORA_PRIO == 6
+    if (slot == 2) __builtin_amdgcn_s_setprio(2); else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+#endif
+#if LORA_STAGGER
+    // a window takes a workgroup ~14 k cycles at three workgroups per CU: a third is ~4.7 k cycles = 73 x 64
+    if (slot == 1) __builtin_amdgcn_s_sleep(73);
+    else if (slot == 2) { __builtin_amdgcn_s_sleep(73); __builtin_amdgcn_s_sleep(73); }
+#endif
+  }
+#endif
   unsigned cur_g = kWaveLocal ? blockIdx.x * kWorkers + wave : blockIdx.x;
   WinCtx cur = window_ctx<N, CONST_OFF>(p, cur_g * GW + wig);
   // CONST_OFF: this thread's chirp and Kaiser taps for the whole sweep
