@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip_demod.so")
 
 OK, EINVAL, EUNSUPPORTED, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4, -5
+NOALLOC_MAX_HANDLES = 16      # include/lora_hip_demod.h: LORA_HIP_NOALLOC_MAX_HANDLES
 WIN_UP, WIN_SFD = 0, 1
 IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED, OUT_PINNED, NO_VAL = 1, 2, 4, 8, 16, 32, 64
 

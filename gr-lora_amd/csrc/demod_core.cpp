@@ -503,6 +503,18 @@ int plan_reads(lora_demod_core *c) {
   return rl;
 }
 
+// The idle log after the call counter went back to c->n_calls (a dry run undone, or the real run resuming at an earlier
+// S_RESET call): runs whose first call lies at or behind the counter go, and the run that began before it loses the calls
+// the undone pass had added in place (a run is one S_DETECT_PREAMBLE call per N samples, numbered consecutively).
+void trim_idle(lora_demod_core *c) {
+  while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
+  if (c->idle.empty()) return;
+  lora_core_idle &r = c->idle.back();
+  const uint64_t kept = c->n_calls - c->idle_calls0.back();             // calls of this run that stay made (>= 1)
+  const uint64_t last = r.first + (kept - 1) * (uint64_t)c->d_num_symbols;
+  if (last < r.last) r.last = last;
+}
+
 // First pass of a plan: the state machine runs ONCE over what is known, as in plan_reads, but keeps what it produces --
 // trace rows, PDUs -- with the header/payload calls answered from predictions (the squelch from A, the bin unknown).
 // After the READ stage has evaluated those windows, every predicted squelch decision is checked against the exact
@@ -534,7 +546,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   const double t_walked = now_s();
   auto to_start = [&]() {
     static_cast<WalkState &>(*c) = saved; c->n_calls = saved_calls;
-    while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
+    trim_idle(c);
   };
   if (rc != LORA_HIP_OK && rc != kShadowStop) { to_start(); return rc; }
   const uint64_t end = c->base + c->total();
@@ -592,7 +604,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   }
   if (from_start) to_start();
   else { c->d_state = LORA_S_RESET; c->pos = rb.pos; c->n_calls = rb.calls; c->n_pdus = saved.n_pdus + rb.pdus; }
-  while (!c->idle_calls0.empty() && c->idle_calls0.back() >= c->n_calls) { c->idle.pop_back(); c->idle_calls0.pop_back(); }
+  trim_idle(c);
   P.rd_cur = 0;
   c->t_stage[3] += t3 - t2; c->t_cb += now_s() - t3;
   if (c->timing) fprintf(stderr, "[core]   first pass: state machine %.3f ms (%llu calls) | run list %.3f | check + fill in %.3f (%zu predicted calls)\n",

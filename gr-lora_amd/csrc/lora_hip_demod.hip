@@ -16,11 +16,14 @@ using lora_hip::KParams;
 
 // Scratch of lora_hip_demod_batch_strided_noalloc (callers that cannot allocate): the window-group ticket counters
 // of the persistent kernels, the only device memory they use beyond the caller's inputs and outputs and the
-// handle's tables.  One copy per GPU the library runs on, held until the process ends.  In host code this name is
-// only a stand-in for hipGetSymbolAddress: what reaches a kernel or a memset is the per-device address kept in
-// g_scratch_ptr, taken once per device at lora_hip_demod_create.
+// handle's tables.  One copy per GPU the library runs on, held until the process ends: kScratchSlots slots of 4 KiB,
+// one per handle (claimed at lora_hip_demod_create, given back at lora_hip_demod_destroy), so that two blocks on two
+// scheduler threads never share counters.  In host code this name is only a stand-in for hipGetSymbolAddress: what
+// reaches a kernel or a memset is the per-device address kept in g_scratch_ptr, taken once per device at
+// lora_hip_demod_create.
 constexpr size_t kScratchWords = lora_hip::kWaveTicketQueues * lora_hip::kTicketStride;   // 32 counters, 128 B apart: 4 KiB
-static __device__ __align__(256) unsigned scratch[kScratchWords];
+constexpr int kScratchSlots = LORA_HIP_NOALLOC_MAX_HANDLES;                                // 16 slots: 64 KiB per GPU
+static __device__ __align__(256) unsigned scratch[kScratchSlots * kScratchWords];
 
 struct lora_hip_demod {
   int device = 0;
@@ -39,8 +42,11 @@ struct lora_hip_demod {
   // results for host callers: one device block [n_win floats | n_win u16] and its pinned mirror, so that
   // a call costs one device-to-host copy
   unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
-  unsigned *d_ticket = nullptr;          // window-group ticket counter of the persistent kernel
-  bool ticket_dirty = false;             // the last launch failed: clear the counters before the next
+  unsigned *d_ticket = nullptr;          // window-group ticket counters of the persistent kernel (the allocating entry points)
+  bool ticket_dirty = false;             // a launch on d_ticket may have failed: clear those counters before the next
+  int scratch_slot = -1;                 // this handle's slot of the per-device `scratch` (-1: all were taken at create)
+  bool scratch_dirty = false;            // the same for the handle's scratch slot (each buffer has its own flag)
+  long fault_at = -1, n_launch = 0;      // LORA_HIP_FAULT=n: test hook, the n-th launch on the handle fails and leaves its counters undefined
   unsigned long long *d_dbg = nullptr;   // LORA_STAMPS builds only
   char hip_err[256] = {0};
   const char *kernel_name = "";
@@ -53,9 +59,13 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 unsigned *g_scratch_ptr[kMaxDevices] = {nullptr};   // device address of `scratch` on each GPU, by device index
+unsigned g_scratch_used[kMaxDevices] = {0};         // bit s: slot s of that GPU's scratch belongs to a live handle
+unsigned g_scratch_stale[kMaxDevices] = {0};        // bit s: slot s was given back with counters that may not be zero
 
 int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
-  if (h) { snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e)); h->ticket_dirty = true; }
+  // any HIP failure on the handle may have been a launch that died half way: both counter buffers are suspect, and each
+  // is cleared (and its own flag reset) by the next launch that uses it
+  if (h) { snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e)); h->ticket_dirty = true; h->scratch_dirty = true; }
   return LORA_HIP_EHIP;
 }
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
@@ -153,7 +163,16 @@ bool pick_variant(unsigned sf, unsigned f, Variant *v) {
   }
 }
 
-int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
+// own_ticket: the counters are the handle's d_ticket (allocating entry points); otherwise the handle's scratch slot
+int launch(lora_hip_demod *h, KParams &p, const bool own_ticket) {
+  unsigned *const ticket = own_ticket ? h->d_ticket : g_scratch_ptr[h->device] + (size_t)h->scratch_slot * kScratchWords;
+  bool &dirty = own_ticket ? h->ticket_dirty : h->scratch_dirty;
+#if LORA_CLOCK || LORA_STAMPS
+  if (!own_ticket) {   // the diagnostic builds allocate and synchronise in here: not what the no-allocation entry point promises
+    snprintf(h->hip_err, sizeof h->hip_err, "lora_hip_demod_batch_strided_noalloc is not available in LORA_CLOCK / LORA_STAMPS builds");
+    return LORA_HIP_EUNSUPPORTED;
+  }
+#endif
   Variant v;
   if (!pick_variant(h->sf, h->fft_factor, &v)) return LORA_HIP_EUNSUPPORTED;
   if (p.n_win == 0) return LORA_HIP_OK;
@@ -191,10 +210,14 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   // The counters must be zero at the launch.  They are when the buffer is new (create() clears the handle's own; the
   // library's __device__ array starts as zeros) and after every launch that ran to its end: the kernel's last workgroup
   // clears them.  A launch that failed leaves them undefined, so the next one clears them itself.
-  if (h->ticket_dirty) {
+  if (dirty) {
     hipError_t em = hipMemsetAsync(ticket, 0, kScratchWords * sizeof(unsigned), h->stream);
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
-    h->ticket_dirty = false;
+    dirty = false;
+  }
+  if (h->fault_at > 0 && ++h->n_launch == h->fault_at) {   // test hook: what a launch that died half way leaves behind
+    (void)hipMemsetAsync(ticket, 0xA5, kScratchWords * sizeof(unsigned), h->stream);
+    return hip_fail(h, hipErrorLaunchFailure, "kernel launch (LORA_HIP_FAULT test hook)");
   }
   p.ticket = ticket;
   p.twist = h->d_twist; p.fr = h->fft_factor;
@@ -220,7 +243,7 @@ int launch(lora_hip_demod *h, KParams &p, unsigned *ticket) {
   }
 #endif
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { h->ticket_dirty = true; return hip_fail(h, e, "kernel launch"); }
+  if (e != hipSuccess) { dirty = true; return hip_fail(h, e, "kernel launch"); }
   return LORA_HIP_OK;
 }
 
@@ -305,6 +328,7 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   Variant v;
   pick_variant(sf, fft_factor, &v);
   h->kernel_name = v.name_const;   // the kernel of the steady-state sweep
+  if (const char *e = getenv("LORA_HIP_FAULT")) h->fault_at = atol(e);
   if (const char *e = getenv("LORA_HIP_BLOCKS_PER_CU")) { int b = atoi(e); if (b >= 1 && b <= 8) h->blocks_per_cu = (unsigned)b; }   // tuning knob
 
   const size_t n = h->n, m = h->m;
@@ -398,6 +422,16 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
       if (e != hipSuccess || !sp) { hip_fail(h, e, "hipGetSymbolAddress(scratch)"); return fail(LORA_HIP_EHIP); }
       g_scratch_ptr[device] = sp;
     }
+    // this handle's slot of the scratch; none left is not an error here (only the no-allocation entry point needs one)
+    for (int sl = 0; sl < kScratchSlots; sl++) {
+      if (!(g_scratch_used[device] >> sl & 1u)) {
+        g_scratch_used[device] |= 1u << sl;
+        h->scratch_slot = sl;
+        h->scratch_dirty = g_scratch_stale[device] >> sl & 1u;
+        g_scratch_stale[device] &= ~(1u << sl);
+        break;
+      }
+    }
   }
   // kernels with more dynamic LDS than the runtime's default limit need the opt-in
   if (v.lds > 48 * 1024 || v.lds_const > 48 * 1024) {
@@ -413,6 +447,12 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
+  if (h->scratch_slot >= 0 && h->device < kMaxDevices) {   // the slot goes back; the next owner clears it if this one left it undefined
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_used[h->device] &= ~(1u << h->scratch_slot);
+    if (h->scratch_dirty) g_scratch_stale[h->device] |= 1u << h->scratch_slot;
+    h->scratch_slot = -1;
+  }
   (void)hipFree(h->d_up); (void)hipFree(h->d_down); (void)hipFree(h->d_win); (void)hipFree(h->d_tw); (void)hipFree(h->d_twist);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_desc); (void)hipFree(h->d_runs); (void)hipFree(h->d_out); (void)hipFree(h->d_ticket);
   if (h->h_out) (void)hipHostFree(h->h_out);
@@ -532,7 +572,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
-  if ((rc = launch(h, p, h->d_ticket)) != LORA_HIP_OK) return rc;
+  if ((rc = launch(h, p, true)) != LORA_HIP_OK) return rc;
   if (!out_dev) {
     const size_t idx_off = n_win * 4;
     if (flags & LORA_HIP_OUT_PINNED) {
@@ -640,6 +680,11 @@ int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq
   if (pos0 > n_samples || n_samples - pos0 < h->n) return LORA_HIP_EINVAL;
   if (count > 1 && stride != 0 && (count - 1) > (n_samples - pos0 - h->n) / stride) return LORA_HIP_EINVAL;
   if (h->device >= kMaxDevices || !g_scratch_ptr[h->device]) return LORA_HIP_ENODEVICE;   // set by create() on this device
+  if (h->scratch_slot < 0) {
+    snprintf(h->hip_err, sizeof h->hip_err, "lora_hip_demod_batch_strided_noalloc: all %d scratch slots of GPU %d were taken when this handle was created",
+             kScratchSlots, h->device);
+    return LORA_HIP_ENOMEM;
+  }
   DeviceGuard guard(h->device);
   HIP_TRY(h, guard.err);
   KParams p;
@@ -652,8 +697,9 @@ int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)count;
-  // enqueue only (a memset of the scratch and the kernel, on the handle's stream): no allocation, no synchronisation
-  return launch(h, p, g_scratch_ptr[h->device]);
+  // enqueue only, on the handle's stream: the kernel (its last workgroup returns the counters to zero), in front of it a
+  // memset of the handle's 4 KiB slot only after a failed launch; no allocation, no synchronisation
+  return launch(h, p, false);
 }
 
 }  // extern "C"

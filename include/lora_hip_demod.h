@@ -155,17 +155,26 @@ LORA_HIP_API void lora_hip_host_free(void *p);
  * harnesses that forbid allocation.  Same windows, same kernels and same results, bit for bit, as
  * lora_hip_demod_batch_strided with LORA_HIP_IQ_ON_DEVICE | LORA_HIP_OUT_ON_DEVICE | LORA_HIP_ASYNC; the only device
  * memory the kernels use beyond the caller's buffers and the handle's tables, their window-group ticket counters
- * (4 KiB), lies in a file-scope __device__ array of the library instead of a buffer the handle allocated.
+ * (4 KiB), lies in a file-scope __device__ array of the library (LORA_HIP_NOALLOC_MAX_HANDLES slots of 4 KiB = 64 KiB
+ * per GPU, held until the process ends) instead of a buffer the handle allocated.
  *   - iq_dev, max_idx_dev and max_val_dev are device pointers on the handle's GPU; nothing is copied to or from
  *     the host and nothing is allocated or freed (no hipMalloc/hipFree/hipHostMalloc, no growth of staging buffers).
  *   - The call only enqueues the kernel on the handle's stream (lora_hip_demod_set_stream); the caller synchronises.
  *     The counters are zero when the library is loaded and the kernel's last workgroup returns them to zero, so no
  *     memset is enqueued (only after a HIP error on this handle does the next call clear them first).
  *   - count above LORA_HIP_NOALLOC_MAX_WINDOWS is refused with LORA_HIP_EINVAL (text in lora_hip_last_hip_error).
- *   - Every call on one GPU shares that GPU's scratch array, whatever the handle: calls that overlap in time on one
- *     GPU (different streams or threads) race on the counters.  Calls queued on one stream are safe.
+ *   - Every handle owns one slot of its GPU's scratch array, claimed at lora_hip_demod_create and given back at
+ *     lora_hip_demod_destroy: calls on different handles never share counters, whatever their streams or threads.  A
+ *     handle created while LORA_HIP_NOALLOC_MAX_HANDLES others are alive on the same GPU has no slot: every other entry
+ *     point works on it, this one returns LORA_HIP_ENOMEM (text in lora_hip_last_hip_error).
+ *   - Calls on ONE handle share that handle's slot, which keeps the last call's state (zeros after a launch that ran to
+ *     its end): queued on one stream they are ordered and safe; overlapping in time (the stream changed between two
+ *     calls that are both still running) they race on the counters.  A handle is used by one thread at a time anyway.
+ *   - Diagnostic builds of the library (LORA_CLOCK, LORA_STAMPS) allocate inside a launch; there this entry point
+ *     returns LORA_HIP_EUNSUPPORTED.
  */
 #define LORA_HIP_NOALLOC_MAX_WINDOWS ((size_t)1 << 30)
+#define LORA_HIP_NOALLOC_MAX_HANDLES 16
 LORA_HIP_API int lora_hip_demod_batch_strided_noalloc(lora_hip_demod_t *h, const lora_c32 *iq_dev,
                                                       size_t n_samples, uint64_t pos0, uint64_t stride,
                                                       size_t count, unsigned chirp_off,

@@ -202,3 +202,27 @@ def test_gpu_seek_and_idle_log_match_the_oracle():
     w.close()
     assert lists(got["pdus"]) == lists(want["pdus"]) and len(want["pdus"]) >= 3
     assert np.array_equal(got["idle"], want["idle"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plan", [1, 2])
+@pytest.mark.parametrize("chunk_symbols", [37, 1500, 4000])
+def test_gpu_idle_log_with_chunked_feed_matches_the_oracle(plan, chunk_symbols):
+    """Multi-call streaming with a plan: a work() call that begins while the block is already in S_DETECT_PREAMBLE runs its
+    first pass on top of the open idle run; undoing that pass (a long idle chunk with no S_RESET call, a rollback) must
+    give the run back as it was.  The log stays sorted, disjoint and equal to the oracle's for any chunking."""
+    import gr_lora_amd as g
+    cap, _ = capture(77, n_packets=8, max_gap=400, snr_db=9)        # long idle stretches between packets
+    ref, tr, _, _ = oracle.Demod(SF, False, cases.BETA, F).stream(cap, want_trace=True)
+    want = idle_from_trace(tr, N)
+    blk = g.demod(SF, False, cases.BETA, F, plan=plan)
+    pdus = []
+    step = chunk_symbols * N + 13
+    for a in range(0, len(cap), step):
+        pdus += blk.work(cap[a:a + step])
+        log = blk.idle_log()
+        assert np.all(log[1:, 0] > log[:-1, 1]) and np.all(log[:, 1] >= log[:, 0])      # sorted and disjoint after every call
+    got = blk.idle_log().copy()
+    blk.close()
+    assert lists(pdus) == lists(ref) and len(ref) >= 5
+    assert np.array_equal(got, want)
