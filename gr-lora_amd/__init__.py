@@ -6,4 +6,4 @@ from . import capi  # noqa: F401
 from .capi import HipDemod, LoraHipError, make_chirp_tables, make_kaiser, make_desc  # noqa: F401
 from .demod import demod  # noqa: F401,E402
 from .channelizer import channelizer, create_taps  # noqa: F401,E402
-from .decode import decode  # noqa: F401,E402
+from .decode import decode, whitening_from_header  # noqa: F401,E402

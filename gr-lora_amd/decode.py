@@ -9,10 +9,25 @@ code).  The whitening sequence is an argument (reference: include/lora/lora.h:29
 lib/decode_impl.cc:72-113): those tables are reference source and are not part of this package.
 """
 import ctypes as C
+import re
+import warnings
 
 import numpy as np
 
 from . import capi
+
+
+def whitening_from_header(path, spreading_factor, low_data_rate):
+    """The sequence the reference's block would select (lib/decode_impl.cc:72-113), read from a copy of its table header
+    (include/lora/lora.h) that the USER supplies: `const unsigned short whitening_sequence_sf<SF>_[ldr_]implicit[N] = {...};`.
+    The tables themselves are reference source and do not ship with this package."""
+    name = f"whitening_sequence_sf{int(spreading_factor)}_{'ldr_' if low_data_rate else ''}implicit"
+    with open(path) as f:
+        for line in f:
+            m = re.match(r"\s*const unsigned short " + name + r"\[\d+\]\s*=\s*\{(.*)\};", line)
+            if m:
+                return np.array([int(t, 0) for t in m.group(1).split(",") if t.strip()], np.uint16)
+    raise KeyError(f"{name} not found in {path}")
 
 
 class decode:
@@ -26,7 +41,15 @@ class decode:
             raise ValueError("code_rate must be in 1..4")
         self.spreading_factor, self.code_rate = int(spreading_factor), int(code_rate)
         self.low_data_rate, self.header = bool(low_data_rate), bool(header)   # header: accepted and ignored, as :115-119
-        self._w = None if whitening_sequence is None else np.ascontiguousarray(whitening_sequence, np.uint16)
+        # DIVERGENCE from the reference, stated in INTEGRATION.md: lora.decode(sf, cr, ldr, header) always de-whitens with the
+        # table it selects from sf and low_data_rate (:72-113, :155-162); those tables are not in this package, so the
+        # sequence is an argument.  None (the default) de-whitens nothing and warns; False says "none" on purpose.
+        if whitening_sequence is None:
+            warnings.warn("decode(): no whitening_sequence given -- the reference block would de-whiten with its table for this "
+                          "sf/low_data_rate, this one will not (pass the sequence, e.g. whitening_from_header(<your lora.h>, sf, "
+                          "ldr), or whitening_sequence=False to silence this)", stacklevel=2)
+        no_seq = whitening_sequence is None or whitening_sequence is False
+        self._w = None if no_seq else np.ascontiguousarray(whitening_sequence, np.uint16)
         self._handlers = []
 
     @staticmethod

@@ -2,6 +2,8 @@
 // (lib/demod_impl.cc:58-60, :74-75, :420-422) and hands every new input item to the core, which
 // keeps its own 3N-1 samples of look-behind; GNU Radio's history mechanism is therefore not used
 // (history() stays 1) and every call consumes all it was given.
+#include <cstdlib>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <gnuradio/io_signature.h>

@@ -54,7 +54,7 @@ def test_c_abi_equals_restatement(sf, ldr, g, codec):
             assert bytes(d.work(s)) == codec.decode_pdu(sf, cr, ldr, w, s.tolist()), (sf, ldr, cr, n)
         # without a sequence: no de-whitening at all
         s = rng.integers(0, 1 << sf, 64).astype(np.uint16)
-        assert bytes(g.decode(sf, cr, ldr).work(s)) == codec.decode_pdu(sf, cr, ldr, None, s.tolist())
+        assert bytes(g.decode(sf, cr, ldr, whitening_sequence=False).work(s)) == codec.decode_pdu(sf, cr, ldr, None, s.tolist())
 
 
 @pytest.mark.parametrize("ldr", [False, True])
@@ -110,6 +110,27 @@ def test_argument_checks(g):
         g.decode(13, 4)
     with pytest.raises(ValueError):
         g.decode(8, 0)
+
+
+def test_missing_whitening_sequence_warns_and_header_loader(g, tmp_path):
+    """lora.decode(sf, cr, ldr, header) de-whitens with its own table; this mirror cannot (the tables are reference source), so
+    the four-argument form warns instead of silently returning other bytes.  The loader reads the table from a header the
+    user supplies (format of include/lora/lora.h:29-46)."""
+    import warnings
+    with pytest.warns(UserWarning, match="whitening_sequence"):
+        g.decode(8, 4, False, False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        g.decode(8, 4, False, False, whitening_sequence=False)            # "none" on purpose: silent
+        g.decode(8, 4, False, False, whitening_sequence=[1, 2, 3])
+    w = synthetic_whitening(9, 3)[:279]
+    hdr = tmp_path / "lora.h"
+    hdr.write_text("// made by the test\n  const unsigned short whitening_sequence_sf9_implicit[279] = {" + ", ".join(hex(int(v)) for v in w) + "};\n"
+                   "  const unsigned short whitening_sequence_sf9_ldr_implicit[279] = {" + ", ".join(str(int(v) ^ 1) for v in w) + "};\n")
+    assert np.array_equal(g.whitening_from_header(str(hdr), 9, False), w)
+    assert np.array_equal(g.whitening_from_header(str(hdr), 9, True), w ^ 1)
+    with pytest.raises(KeyError):
+        g.whitening_from_header(str(hdr), 10, False)
 
 
 def golden_cases():
