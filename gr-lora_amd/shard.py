@@ -103,6 +103,40 @@ def gather_pdus(local, n_items, dst=0):
 LATTICE = 16     # OVERLAP_FACTOR, lib/demod_impl.cc:36: read indices are multiples of N/16
 
 
+class RangeSource:
+    """A capture that is read by range: load(lo, hi) -> complex64 samples [lo, hi) of the capture (a file reader, a
+    generator, a network fetch).  Everything in this module only takes len() and contiguous slices of `samples`, so a
+    rank that is handed a RangeSource holds its own time segment plus the overlap and nothing else (a numpy array or
+    a numpy.memmap works the same way)."""
+
+    def __init__(self, n_samples, load):
+        self.n_samples, self.load = int(n_samples), load
+        self.loaded = 0                    # samples read so far (ranges that are walked again count again)
+        self.lo_min, self.hi_max = None, None     # the part of the capture this process ever touched
+
+    def __len__(self):
+        return self.n_samples
+
+    @property
+    def spanned(self):
+        """Samples between the first and the last one this process ever read."""
+        return 0 if self.lo_min is None else self.hi_max - self.lo_min
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("RangeSource is read in contiguous slices only")
+        lo, hi, _ = sl.indices(self.n_samples)
+        hi = max(hi, lo)
+        self.loaded += hi - lo
+        if hi > lo:
+            self.lo_min = lo if self.lo_min is None else min(self.lo_min, lo)
+            self.hi_max = hi if self.hi_max is None else max(self.hi_max, hi)
+        x = np.ascontiguousarray(self.load(lo, hi), np.complex64)
+        if len(x) != hi - lo:
+            raise ValueError(f"load({lo}, {hi}) returned {len(x)} samples")
+        return x
+
+
 def framed_slice(samples, sf, lo, hi):
     """Samples [lo, hi) of the framed stream = 3N-1 zeros (set_history(3N), lib/demod_impl.cc:103)
     followed by the capture."""
@@ -342,7 +376,8 @@ def chain_segments(trajs, cuts, sf, walker=None):
 
 
 class BlockWalker:
-    """walker() on a demod block (gr-lora_amd.demod): seek, feed the framed samples, read PDUs and idle log."""
+    """walker() on a demod block (gr-lora_amd.demod): seek, feed the framed samples, read PDUs and idle log.
+    samples: a numpy array, a numpy.memmap or a RangeSource -- only the ranges a walk covers are ever read."""
 
     def __init__(self, samples, sf, make_block, on_device=False):
         self.samples, self.sf, self.blk, self.on_device = samples, sf, make_block(), on_device

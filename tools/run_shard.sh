@@ -1,7 +1,6 @@
-set -e
-cd /root/repo
-mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/test_shard_replay.py tests/test_time_shard.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/shard_test.log 2>&1 || { tail -40 gpurun_out/shard_test.log; exit 1; }
-tail -3 gpurun_out/shard_test.log
-timeout -k 10 600 python -u tools/run_configs.py 4 > gpurun_out/cfg4.log 2>&1 || { tail -30 gpurun_out/cfg4.log; exit 1; }
-cat gpurun_out/cfg4.log
+#!/bin/bash
+# tools/run_shard.sh N [N ...] : the sharded paths of BASELINE configs[3] and configs[4] at full size on N ranks (one JSON line per N).
+# On an 8-GPU node: tools/run_shard.sh 1 2 4 8     (rank r uses GPU r % device count, so a 1-GPU box rehearses any N)
+for n in "$@"; do
+  timeout -k 10 1100 python3 tools/run_shard.py $n ${SHARD_ARGS:-} || exit 1
+done
