@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 namespace lora_chan {
@@ -38,6 +40,9 @@ struct CParams {
   float2 *out;
   unsigned long long n_out;
   const float *filt, *dfilt;           // [nfilts][K], stored reversed as fir_filter::set_taps does
+  const float2 *bank2;                 // chan_arm_kernel: the two banks interleaved, {f0, f1}[nfilts][K]
+  unsigned tile_cap;                   // chan_arm_kernel: float2 slots of the LDS tile (the order list lies behind it)
+  unsigned row_pitch;                  // chan_arm_kernel: slots per row of the de-interleaved tile (sample i sits in row i mod 2^E)
   unsigned K, nfilts;
   // closed form of the reference's index recurrence (exact, see chan_work_chunk): output m sits at polyphase
   // position p0 + m*dec + ((a0 + m*a) >> 24) relative to in[0], with d_acc = ((a0 + m*a) mod 2^24) / 2^24
@@ -192,6 +197,249 @@ __global__ __launch_bounds__(kBlock) void chan_arb_kernel(const CParams p) {
         o.x = re0 + re1 * a; o.y = im0 + im1 * a;
       }
       p.out[m] = o;
+    }
+  }
+}
+
+
+// ---- any rate, outputs grouped by arm (nfilts <= kArmMaxFilts) -------------------------------------------------
+// chan_arb_kernel gives every lane its own arm, so every tap is a per-lane LDS read beside the sample's: two LDS reads
+// per tap and output, and the LDS -- one pipe for the CU's four SIMDs -- binds (measured: 57 % busy, a third of it bank
+// conflicts).  Here a tile's outputs are first sorted by arm (a counting sort in LDS: one pass counts, one pass
+// scatters their numbers into `order`, each arm's run padded to whole waves), and a wave then works on 64 outputs of
+// ONE arm: the tap pair {f0[k], f1[k]} is the same for all its lanes and comes through the scalar data path (constant
+// address space, s_load into SGPRs -- reads only), the banks need no LDS at all (the tile of samples is about three
+// times as big instead), and what is left per tap and lane is one LDS read and the eight multiplies and adds of the
+// reference's sums -- same products, same order (sequential accumulation, product rounded before the add, o0 + o1*d_acc),
+// so the result is still bit-identical to the oracle's float evaluation.  Which lane computes which output has no
+// influence on an output's value.
+#ifndef LORA_ARM_BLOCK
+#define LORA_ARM_BLOCK 512
+#endif
+#ifndef LORA_ARM_WG_PER_CU
+#define LORA_ARM_WG_PER_CU 2
+#endif
+#ifndef LORA_ARM_ABL
+#define LORA_ARM_ABL 0   // timing-only ablations (wrong results): 1 taps are constants (no scalar loads), 2 samples are constants (no LDS
+                         // reads in the filter loop), 4 no tile load from HBM, 8 no filter loop (load + sort + store only), 16 no sort (identity order)
+#endif
+constexpr int kArmBlock = LORA_ARM_BLOCK;          // threads per workgroup
+constexpr int kArmWgPerCu = LORA_ARM_WG_PER_CU;    // resident workgroups per CU: independent tiles in different phases (loading, sorting, filtering)
+constexpr unsigned kArmMaxFilts = 64;
+typedef const __attribute__((address_space(4))) float *const_f_ptr;     // constant address space: uniform loads are scalar loads
+// one ds_read_b64 per sample: paired into ds_read2_b64 the same bytes take twice the LDS cycles (MI355X_MICROARCH.md, LDS
+// table), and the LDS is the one pipe all four SIMDs share; a volatile LDS access is never paired
+// (addressed by a 32-bit LDS byte address: through generic pointers every read drags a null check and 64-bit arithmetic along)
+__device__ __forceinline__ float2 lds_ld(const unsigned lds_byte_addr) {
+  if (LORA_ARM_ABL & 2) return make_float2((float)lds_byte_addr, 1.0f);
+  typedef float lds_v2f __attribute__((ext_vector_type(2)));
+  const lds_v2f t = *(const volatile __attribute__((address_space(3))) lds_v2f *)(size_t)lds_byte_addr;
+  return make_float2(t.x, t.y);
+}
+// E: the tile is stored de-interleaved into 2^E rows, sample i (relative to the tile's first) in row i mod 2^E at slot i >> E.
+// Consecutive outputs of one arm start a near-constant number S of inputs apart; the lanes of a wave then read samples
+// S apart, and an even S puts 32 lanes on 16 (S = 2 mod 4) or 8 bank pairs: every ds_read_b64 takes twice or four times its
+// cycles, which makes the LDS, not the multiplies, the bound (measured at rate 0.3, S = 10: 131 M conflict cycles of 258 M).
+// With 2^E the power of two in S all lanes stay in one row and S >> E apart in it -- odd, so 32 lanes hit 32 different
+// bank pairs.  The host picks E from the rate (arm_deinterleave); any E gives the same results.
+template <bool ROT, bool INTERP, int E>
+__global__ __launch_bounds__(kArmBlock, (kArmBlock / 64) * kArmWgPerCu / 4) void chan_arm_kernel(const CParams p) {
+  constexpr unsigned NR = 1u << E;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *tile = reinterpret_cast<float2 *>(smem_raw);                             // [tile_cap]
+  const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;   // its LDS byte address
+  unsigned short *order = reinterpret_cast<unsigned short *>(tile + p.tile_cap);   // [tile_out + 63*nfilts]: runs of one arm
+  unsigned short *xoff = order + (p.tile_out + 63u * p.nfilts);                    // [tile_out]: where an output's window starts in the tile
+  unsigned char *arm_of_out = reinterpret_cast<unsigned char *>(xoff + p.tile_out);   // [tile_out]
+  constexpr int kWaves = kArmBlock / 64;
+  __shared__ unsigned cntw[kWaves][kArmMaxFilts];   // outputs per (wave's share of the tile, arm); then each wave's write cursors
+  __shared__ unsigned n_chunks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned K = p.K, nf = p.nfilts;
+  constexpr unsigned long long kMask = (1ull << kFracBits) - 1;
+  auto pos = [&](const unsigned long long m) -> unsigned long long {
+    return p.p0 + m * p.dec + ((p.a0 + m * p.a) >> kFracBits);
+  };
+  // position -> (input index, arm); the filter count is a power of two in every flowgraph (32), which spares the 64-bit division
+  const bool pow2 = (nf & (nf - 1)) == 0;
+  const unsigned sh = 31u - (unsigned)__builtin_clz(nf);
+  auto arm_of = [&](const unsigned long long P) -> unsigned { return pow2 ? ((unsigned)P & (nf - 1)) : (unsigned)(P % nf); };
+  auto in_of = [&](const unsigned long long P) -> long long { return (long long)(pow2 ? (P >> sh) : (P / nf)); };
+  const unsigned long long n_tiles = (p.n_out + p.tile_out - 1) / p.tile_out;
+  const unsigned H = p.row_pitch;
+  auto slot = [&](const unsigned i) -> unsigned { return (i & (NR - 1)) * H + (i >> E); };      // sample i of the tile -> LDS slot
+  for (int i = tid; i < kWaves * (int)kArmMaxFilts; i += kArmBlock) (&cntw[0][0])[i] = 0;
+  for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const unsigned long long m0 = t * p.tile_out;
+    const unsigned long long m1 = (m0 + p.tile_out < p.n_out) ? m0 + p.tile_out : p.n_out;
+    const unsigned nt = (unsigned)(m1 - m0);
+    // the tile's first output: everything about output m0 + i follows from these in a few 32x32 -> 64 bit products
+    const unsigned long long P0 = pos(m0), A0 = (p.a0 + m0 * p.a) & kMask;
+    const unsigned arm0 = arm_of(P0);
+    const long long in0 = in_of(P0), s_lo = in0 - (long long)(K - 1);
+    const int span = (int)(in_of(pos(m1 - 1)) - s_lo + 1);
+    const unsigned dec32 = (unsigned)p.dec, a32 = (unsigned)p.a;    // both below 2^32 (the host checks dec; a < 2^24): 32 x 32 -> 64 bit products
+    auto rel_of = [&](const unsigned i) -> unsigned long long {       // pos(m0 + i) - P0 + arm0
+      return (unsigned long long)arm0 + (unsigned long long)i * dec32 + ((A0 + (unsigned long long)i * a32) >> kFracBits);
+    };
+    __syncthreads();                                             // the previous tile's readers are done; the counters are zero
+    // Tile load.  All but the stream's first and last tiles lie wholly inside this call's input: then the loads need no
+    // selection between carry, input and zero, and go out eight per thread before the first is waited for (as one load,
+    // one wait, one store per sample -- what the general form compiles to -- a tile paid fourteen HBM round trips).
+    auto put = [&](const int i, float2 x) {
+      if (ROT) {
+        // the exact phase of sample s (a double), reduced to (-pi, pi], then a float sine and cosine: the phasor is
+        // within 1e-7 of the exact one (the reference's own product chain wanders 8e-6 around it)
+        const double a = p.phase0 + p.inc * (double)(s_lo + i);
+        const float r = (float)(a - 6.283185307179586476925 * rint(a * 0.15915494309189533577));
+        float sn, cs;
+        sincosf(r, &sn, &cs);
+        x = rotate(x, make_float2(cs, sn));
+      }
+      tile[slot((unsigned)i)] = x;
+    };
+    if (!(LORA_ARM_ABL & 4) && s_lo >= 0 && s_lo + span <= p.n_in) {
+      const float2 *__restrict__ src = p.in + s_lo;
+      constexpr int U = 8;
+      for (int i0 = tid; i0 < span; i0 += kArmBlock * U) {
+        float2 tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int i = i0 + u * kArmBlock;
+          tmp[u] = src[i < span ? i : span - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int i = i0 + u * kArmBlock;
+          if (i < span) put(i, tmp[u]);
+        }
+      }
+    } else {
+      for (int i = tid; i < span; i += kArmBlock) put(i, (LORA_ARM_ABL & 4) ? make_float2((float)i, 1.0f) : fetch(p, s_lo + i));
+    }
+    // Sort the tile's outputs by arm, keeping their order inside an arm (consecutive outputs of one arm have window
+    // starts a near-constant stride apart, which spreads a wave's LDS reads over the banks; a random order does not).
+    // Wave w owns the outputs [w*per, (w+1)*per) of the tile.  Pass 1: arm and window start of every output, and how
+    // many outputs of each arm the wave's share holds.
+    const unsigned per = (nt + kWaves - 1) / kWaves;
+    const unsigned w_lo = wave * per, w_hi = (w_lo + per < nt) ? w_lo + per : nt;
+    for (unsigned i = w_lo + lane; i < w_hi; i += 64) {
+      const unsigned long long rel = rel_of(i);
+      const unsigned a = pow2 ? ((unsigned)rel & (nf - 1)) : (unsigned)(rel % nf);
+      const unsigned d_in = (unsigned)(pow2 ? (rel >> sh) : (rel / nf));          // input index relative to in0
+      arm_of_out[i] = (unsigned char)a;
+      xoff[i] = (unsigned short)d_in;                            // window start = in0 + d_in - (K-1) - s_lo = d_in
+      atomicAdd(&cntw[wave][a], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane = arm: its run starts behind the (padded) runs of the arms before it (an exclusive scan over the lanes of
+      // this one wave); inside the run the waves' shares follow each other.  cntw[w][arm] becomes wave w's write cursor.
+      unsigned n_w[kWaves], tot = 0;
+      const bool is_arm = lane < (int)nf;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) { n_w[w] = is_arm ? cntw[w][lane] : 0u; tot += n_w[w]; }
+      const unsigned padded = (tot + 63u) & ~63u;
+      unsigned incl = padded;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      const unsigned off = incl - padded;
+      if (is_arm) {
+        unsigned c = off;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) { cntw[w][lane] = c; c += n_w[w]; }
+        for (unsigned s2 = off + tot; s2 < off + padded; s2++) order[s2] = 0xFFFFu;     // the padding computes nothing
+        if (lane == (int)nf - 1) n_chunks = (off + padded) >> 6;
+      }
+    }
+    __syncthreads();
+    // Pass 2: every output takes the next slot behind its wave's cursor for its arm.  A wave's LDS atomics execute in
+    // program order and, within one instruction, lane after lane, so a wave's share comes out in output order (if some
+    // hardware did not, only the bank spread of the filter loop's reads would change, not a result).
+    for (unsigned i = w_lo + lane; i < w_hi; i += 64) order[atomicAdd(&cntw[wave][arm_of_out[i]], 1u)] = (unsigned short)i;
+    __syncthreads();
+    for (int i = tid; i < kWaves * (int)kArmMaxFilts; i += kArmBlock) (&cntw[0][0])[i] = 0;     // the cursors are spent: zero for the next tile
+    const unsigned nc = n_chunks;
+    for (unsigned c = wave; c < nc; c += kWaves) {
+      const unsigned e = order[c * 64 + lane];
+      const bool valid = e != 0xFFFFu;
+      const unsigned e0 = __builtin_amdgcn_readfirstlane(e);     // a run starts on a wave boundary: lane 0 is never padding
+      const unsigned i = valid ? e : e0;
+      const unsigned arm = __builtin_amdgcn_readfirstlane((unsigned)arm_of_out[i]);   // the same for every lane of the chunk
+      // sample base + NR*j + q of this lane's window sits at LDS byte address row[q] + 8*j
+      const unsigned base = xoff[i];
+      unsigned row[NR];
+#pragma unroll
+      for (unsigned q = 0; q < NR; q++) {
+        const unsigned rq = (base + q) & (NR - 1);
+        row[q] = tile_lds + 8u * (rq * H + ((base + q) >> E));
+      }
+      const const_f_ptr fs = (const_f_ptr)(p.bank2 + (size_t)arm * K);
+      auto f = [&](const unsigned k2) {                                                                      // {f0[k], f1[k]}
+        if (LORA_ARM_ABL & 1) return make_float2(0.5f + (float)k2, 0.25f);
+        return make_float2(fs[2 * k2], fs[2 * k2 + 1]);
+      };
+      // volk_32fc_32f_dot_prod_32fc (generic) twice: sequential float accumulation, product rounded before the add.
+      // Blocks of eight taps, the next block's taps (one s_load_dwordx16) and samples (eight ds_read_b64) requested
+      // before the current block's 64 multiplies and adds: scalar loads return out of order, so every wait on them
+      // is a wait for everything, and a request one block ahead has landed by the time it is waited for.
+      float re0 = 0, im0 = 0, re1 = 0, im1 = 0;
+      auto mac = [&](const float2 tp, const float2 v) {
+        re0 += v.x * tp.x; im0 += v.y * tp.x;
+        if (INTERP) { re1 += v.x * tp.y; im1 += v.y * tp.y; }
+      };
+      constexpr unsigned B = 8;
+      auto load = [&](float2 (&tp)[B], float2 (&v)[B], const unsigned k0) {
+#pragma unroll
+        for (unsigned q = 0; q < B; q++) { tp[q] = f(k0 + q); v[q] = lds_ld(row[q & (NR - 1)] + 8u * (q >> E)); }
+      };
+      auto next_block = [&]() {
+#pragma unroll
+        for (unsigned q = 0; q < NR; q++) row[q] += 8u * (B >> E);
+      };
+      auto comp = [&](const float2 (&tp)[B], const float2 (&v)[B]) {
+#pragma unroll
+        for (unsigned q = 0; q < B; q++) mac(tp[q], v[q]);
+      };
+      unsigned k = 0;
+      const unsigned nb = (LORA_ARM_ABL & 8) ? 0 : K / B;        // full blocks; two register sets take turns (no copies)
+      if (nb) {
+        float2 tA[B], vA[B], tB[B], vB[B];
+        load(tA, vA, 0);
+        unsigned bl = 1;
+        for (; bl + 1 < nb; bl += 2) {
+          next_block(); load(tB, vB, bl * B); comp(tA, vA);
+          next_block(); load(tA, vA, (bl + 1) * B); comp(tB, vB);
+        }
+        if (bl < nb) { next_block(); load(tB, vB, bl * B); comp(tA, vA); comp(tB, vB); }
+        else comp(tA, vA);
+        k = nb * B;
+      }
+      if (k < K && !(LORA_ARM_ABL & 8)) {
+        // the last K mod 8 taps as one more block, requested together (one wait instead of one per tap)
+        const unsigned R = K - k;                                // wave-uniform
+        float2 tp[B], v[B];
+        if (k) {
+#pragma unroll
+          for (unsigned q = 0; q < NR; q++) row[q] += 8u * (B >> E);
+        }
+#pragma unroll
+        for (unsigned q = 0; q < B; q++)
+          if (q < R) { tp[q] = f(k + q); v[q] = lds_ld(row[q & (NR - 1)] + 8u * (q >> E)); }
+#pragma unroll
+        for (unsigned q = 0; q < B; q++)
+          if (q < R) mac(tp[q], v[q]);
+      }
+      float2 o = make_float2(re0, im0);
+      if (INTERP) {                                              // o0 + o1*d_acc
+        const float a = (float)((A0 + (unsigned long long)i * a32) & kMask) * (1.0f / (float)(1u << kFracBits));
+        o.x = re0 + re1 * a; o.y = im0 + im1 * a;
+      }
+      if (valid) p.out[m0 + i] = o;
     }
   }
 }
@@ -426,6 +674,11 @@ struct lora_hip_chan {
   bool force_general = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   float *d_filt = nullptr, *d_dfilt = nullptr;
+  float2 *d_bank2 = nullptr;             // {f0, f1}[nfilts][K] for chan_arm_kernel
+  bool no_arm = false;                   // developer knob LORA_CHAN_NO_ARM=1: keep chan_arb_kernel (A/B)
+  unsigned arm_e = 0;                    // chan_arm_kernel: log2 of the tile's de-interleaving (arm_deinterleave)
+  unsigned arm_tile = 0;                 // chan_arm_kernel: outputs per tile (arm_pick_tile); 0: the kernel is not used
+  float arm_lane_use = 0;                // share of the filter loop's lanes that hold an output at that tile size
   float2 *d_carry[2] = {nullptr, nullptr}; int cur_carry = 0;
   float2 *d_rot_lane = nullptr;
   float2 *d_in = nullptr; size_t cap_in = 0;
@@ -496,6 +749,32 @@ inline size_t arb_bank_bytes(const lora_hip_chan *h) { return (size_t)h->nfilts 
 inline bool arb_fits(const lora_hip_chan *h) {
   return h->frac && !h->force_general && arb_bank_bytes(h) + (size_t)(4 * h->K + 64) * 8 <= kArbLdsBytes;
 }
+// the arm-grouped kernel: closed-form positions, few enough arms for its LDS counters, and a tile that holds at least
+// a quarter wave of outputs per arm beside their input span even when every arm occurs (below that the padding of the runs
+// wastes more lanes than the wave-uniform taps gain)
+constexpr size_t kArmLdsBytes = (160 * 1024) / lora_chan::kArmWgPerCu - (lora_chan::kArmBlock / 64) * 256 - 512;   // dynamic LDS per workgroup (its static counters come on top)
+inline unsigned arm_span(const lora_hip_chan *h, unsigned t) {
+  return (unsigned)(((unsigned long long)(t - 1) * (h->dec_rate + 1)) / h->nfilts + 2 + h->K);
+}
+chan_fn arm_kernel_fn(bool rot, bool interp, int e) {
+#define ARM_E(E) (rot ? (interp ? &lora_chan::chan_arm_kernel<true, true, E> : &lora_chan::chan_arm_kernel<true, false, E>) \
+                      : (interp ? &lora_chan::chan_arm_kernel<false, true, E> : &lora_chan::chan_arm_kernel<false, false, E>))
+  return e == 0 ? ARM_E(0) : e == 1 ? ARM_E(1) : ARM_E(2);
+#undef ARM_E
+}
+// largest t with 8*span(t) [tile] + 2*(t + 63*nfilts) [order] + 3*t [window start, arm] <= kArmLdsBytes (16-bit entries: t < 65535)
+inline unsigned arm_tile_max(const lora_hip_chan *h) {
+  unsigned lo = 0, hi = 60000;
+  while (hi - lo > 1) {
+    const unsigned mid = lo + (hi - lo) / 2;
+    if (((size_t)arm_span(h, mid) + 8) * 8 + 2 * ((size_t)mid + 63 * h->nfilts) + 3 * (size_t)mid + 16 <= kArmLdsBytes) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+inline unsigned arm_tile_out(const lora_hip_chan *h) { return h->arm_tile; }
+inline bool arm_fits(const lora_hip_chan *h) {
+  return h->frac && !h->force_general && !h->no_arm && h->nfilts <= lora_chan::kArmMaxFilts && h->arm_tile >= 64;
+}
 constexpr int kFracBits = lora_chan::kFracBits;
 constexpr unsigned long long kFracMask = (1ull << kFracBits) - 1;
 
@@ -547,6 +826,63 @@ size_t frac_count(const lora_hip_chan *h, size_t n_in, unsigned long long *p0_ou
     if (frac_pos(h, p0, a0, mid) < end) lo = mid; else hi = mid;
   }
   return (size_t)hi;
+}
+
+// chan_arm_kernel's tile layout: the number S of inputs between consecutive outputs of one arm, over the stream's first
+// outputs; when one S clearly dominates, the tile is de-interleaved by the power of two in it (at most 4 rows)
+unsigned arm_deinterleave(const lora_hip_chan *h) {
+  if (!h->frac || h->nfilts > lora_chan::kArmMaxFilts) return 0;
+  std::vector<long long> last(h->nfilts, -1);
+  std::vector<std::pair<unsigned long long, unsigned>> hist;       // (stride, count), a handful of entries
+  unsigned pairs = 0;
+  for (unsigned k = 0; k < 8192; k++) {
+    const u128 P = frac_pos(h, h->j_init, 0, k);
+    const unsigned arm = (unsigned)(P % h->nfilts);
+    const long long in = (long long)(P / h->nfilts);
+    if (last[arm] >= 0) {
+      const unsigned long long sdiff = (unsigned long long)(in - last[arm]);
+      pairs++;
+      bool found = false;
+      for (auto &e : hist) if (e.first == sdiff) { e.second++; found = true; break; }
+      if (!found && hist.size() < 64) hist.push_back({sdiff, 1u});
+    }
+    last[arm] = in;
+  }
+  unsigned long long best = 0; unsigned best_n = 0;
+  for (const auto &e : hist) if (e.second > best_n) { best = e.first; best_n = e.second; }
+  if (best == 0 || best_n * 2 < pairs) return 0;
+  const unsigned tz = (unsigned)__builtin_ctzll(best);
+  return tz > 2 ? 2 : tz;
+}
+
+// chan_arm_kernel's tile size.  A tile's outputs are sorted into runs of one arm, each padded to whole waves, so the share of
+// lanes that do useful work is t / sum_arm ceil64(count_arm): a rate that visits few arms (0.3: three or four) loses
+// nothing, one that visits all of them evenly loses up to half unless a run is just under a multiple of 64 long.  The arm
+// sequence is known in closed form, so the host tries the tile sizes that fit the LDS, counts the arms of the stream's first
+// two tiles for each, and keeps the size with the most useful lanes per tile (large tiles win ties: fewer barriers per output;
+// also counting whole rounds of the workgroup's eight waves was measured and changed nothing: the CU's other workgroup fills in).
+void arm_pick_tile(lora_hip_chan *h) {
+  h->arm_tile = 0; h->arm_lane_use = 0;
+  if (!h->frac || h->nfilts > lora_chan::kArmMaxFilts) return;
+  const unsigned tmax = arm_tile_max(h);
+  if (tmax < 64) return;
+  const unsigned n_sim = 2 * tmax;
+  std::vector<unsigned char> arm(n_sim);
+  for (unsigned k = 0; k < n_sim; k++) arm[k] = (unsigned char)(frac_pos(h, h->j_init, 0, k) % h->nfilts);
+  std::vector<unsigned> cnt(h->nfilts);
+  double best = 0; unsigned best_t = 0;
+  for (unsigned t = tmax; t >= 64 && t >= tmax / 2; t -= (t > 16 ? 8 : t)) {
+    unsigned lanes = 0;
+    for (unsigned tile = 0; tile < 2; tile++) {
+      std::fill(cnt.begin(), cnt.end(), 0u);
+      for (unsigned k = tile * t; k < (tile + 1) * t; k++) cnt[arm[k]]++;
+      for (unsigned c : cnt) lanes += (c + 63u) & ~63u;
+    }
+    const double use = 2.0 * t / (double)lanes;
+    if (use > best * 1.02) { best = use; best_t = t; }          // a smaller tile must gain 2 % to be preferred
+  }
+  if (best < 0.45) return;                                        // below that chan_arb_kernel (one arm per lane) is the better kernel
+  h->arm_tile = best_t; h->arm_lane_use = (float)best;
 }
 
 // fallback positions (i_in*nfilts + j, run_recurrence) are 32-bit: the inputs of one piece must keep them below 2^32
@@ -650,6 +986,16 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
   if (hipMemcpy(h->d_filt, bank.data(), bank_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_dfilt, dbank.data(), bank_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   {
+    std::vector<float2> b2(bank.size());
+    for (size_t i = 0; i < bank.size(); i++) b2[i] = make_float2(bank[i], dbank[i]);
+    if (hipMalloc((void **)&h->d_bank2, b2.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+    if (hipMemcpy(h->d_bank2, b2.data(), b2.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
+  if (const char *e = getenv("LORA_CHAN_NO_ARM")) h->no_arm = atoi(e) != 0;
+  h->arm_e = arm_deinterleave(h);
+  arm_pick_tile(h);
+  if (const char *e = getenv("LORA_CHAN_ARM_E")) { const int v2 = atoi(e); if (v2 >= 0 && v2 <= 2) h->arm_e = (unsigned)v2; }   // developer knob (A/B)
+  {
     std::vector<float2> lane(lora_chan::kBlock);
     for (int t = 0; t < lora_chan::kBlock; t++) lane[t] = make_float2((float)std::cos(h->inc_eff * t), (float)std::sin(h->inc_eff * t));
     if (hipMalloc((void **)&h->d_rot_lane, lane.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
@@ -671,6 +1017,9 @@ int lora_hip_chan_create(lora_hip_chan_t **out, int device, double phase_inc, fl
                          (const void *)&lora_chan::chan_arb_kernel<false, true>, (const void *)&lora_chan::chan_arb_kernel<true, true>};
     for (const void *f : arb)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kArbLdsBytes) != hipSuccess) return fail(LORA_HIP_EHIP);
+    for (int i = 0; i < 12; i++)
+      if (hipFuncSetAttribute((const void *)arm_kernel_fn(i & 1, (i >> 1) & 1, i >> 2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kArmLdsBytes) != hipSuccess) return fail(LORA_HIP_EHIP);
   }
   lora_hip_chan_force_general(h, 0);
   *out = h;
@@ -682,6 +1031,7 @@ int lora_hip_chan_force_general(lora_hip_chan_t *h, int on) {
   h->force_general = on != 0;
   const DecimVariant *v = pick_decim(h);
   if (v) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_decim_kernel<%d,%d>", v->D, v->nch);
+  else if (arm_fits(h)) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_arm_kernel");
   else if (arb_fits(h)) snprintf(h->kernel_name, sizeof h->kernel_name, "chan_arb_kernel");
   else snprintf(h->kernel_name, sizeof h->kernel_name, "chan_general_kernel");
   return LORA_HIP_OK;
@@ -691,7 +1041,7 @@ void lora_hip_chan_destroy(lora_hip_chan_t *h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
-  (void)hipFree(h->d_filt); (void)hipFree(h->d_dfilt); (void)hipFree(h->d_carry[0]); (void)hipFree(h->d_carry[1]);
+  (void)hipFree(h->d_filt); (void)hipFree(h->d_dfilt); (void)hipFree(h->d_bank2); (void)hipFree(h->d_carry[0]); (void)hipFree(h->d_carry[1]);
   (void)hipFree(h->d_rot_lane); (void)hipFree(h->d_in); (void)hipFree(h->d_out); (void)hipFree(h->d_spos); (void)hipFree(h->d_sacc);
   if (h->h_spos) (void)hipHostFree(h->h_spos);
   if (h->h_sacc) (void)hipHostFree(h->h_sacc);
@@ -824,6 +1174,17 @@ static int chan_work_chunk(lora_hip_chan_t *h, const float2 *d_in, size_t n_in, 
         p.rot_lane = h->d_rot_lane;
       }
       hipLaunchKernelGGL(v->fn[rot ? 1 : 0], dim3(blocks), dim3(lora_chan::kBlock), 0, h->stream, p);
+    } else if (mode != 2 && arm_fits(h)) {
+      // outputs grouped by arm, taps through the scalar path: the whole dynamic LDS is tile + order list
+      const unsigned to = arm_tile_out(h);
+      const unsigned e = h->arm_e, span = arm_span(h, to);
+      p.tile_out = to; p.bank2 = h->d_bank2;
+      p.row_pitch = ((span + (1u << e) - 1) >> e) + 1;             // one spare slot per row: a window may end one row-slot further
+      p.tile_cap = p.row_pitch << e;
+      const unsigned long long tiles = (cnt + to - 1) / to;
+      unsigned blocks = (unsigned)h->num_cu * lora_chan::kArmWgPerCu;
+      if (tiles < blocks) blocks = (unsigned)tiles;
+      hipLaunchKernelGGL(arm_kernel_fn(rot, mode == 1, (int)e), dim3(blocks), dim3(lora_chan::kArmBlock), kArmLdsBytes, h->stream, p);
     } else if (mode != 2 && arb_fits(h)) {
       // banks in LDS: outputs per tile = as many as keep the tile's input span in what is left
       const size_t tile_samples = (kArbLdsBytes - arb_bank_bytes(h)) / 8;

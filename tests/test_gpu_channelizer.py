@@ -3,8 +3,9 @@ examples/rx_usrp.grc:489-503, :825-860) against the CPU oracle's restatement of 
 PARITY UNPINNED: the blocks are GNU Radio's, the reference holds no fixture for them (oracle/chan_oracle.h).
 
 Bars:
-  * chan_general_kernel and chan_arb_kernel (the same sums with the filter banks in LDS), rotation off: BIT-EXACT
-    against the oracle's sequential float evaluation (same products, same order) -- any rate, any chunking;
+  * chan_general_kernel, chan_arm_kernel (outputs grouped by arm, taps through the scalar path; the kernel fractional rates
+    run) and chan_arb_kernel (banks in LDS, one arm per lane; its fallback), rotation off: BIT-EXACT against the oracle's
+    sequential float evaluation (same products, same order) -- any rate, any chunking;
   * chan_decim_kernel (whole-number decimation; FMA, per-component partial sums): within 1e-5 of the output
     RMS of the oracle's double-precision evaluation -- the float oracle itself sits at a few 1e-7 from it;
   * rotation on: the device turns sample n by exactly n times the angle of the reference's float increment;
@@ -102,9 +103,14 @@ def test_decim_kernel_within_tolerance(d, atten, g):
     q8 = -(-(-(-ch.taps_per_filter // d)) // 8)
     whole = ch.flt_rate == 0.0 and ch.dec_rate == 32 * d          # 1/7 as a float makes 32/rate = 223.99998: fractional
     fast = whole and (q8 <= 4 if d in (2, 4, 8, 16) else q8 == 3)  # other decimations: the 100 dB design's tap count only
-    assert ch.kernel_name == (f"chan_decim_kernel<{d},{max(q8, 2)}>" if fast else "chan_arb_kernel")
+    if fast:
+        assert ch.kernel_name == f"chan_decim_kernel<{d},{max(q8, 2)}>"
+    else:
+        assert ch.kernel_name == "chan_arm_kernel"
     got = ch.work(x)
     assert len(got) == len(want)
+    if not fast:
+        assert np.array_equal(got, want_f)     # the arm-grouped kernel keeps the reference's order: bit for bit
     e_gpu, e_cpu = rel_max(got, want), rel_max(want_f, want)
     print(f"D={d} atten={atten} {ch.kernel_name}: max err / rms  gpu {e_gpu:.2e}  float oracle {e_cpu:.2e}")
     assert e_gpu <= 1e-5
@@ -124,19 +130,25 @@ def test_decim_kernel_within_tolerance(d, atten, g):
     ch.close()
 
 
+@pytest.mark.parametrize("kernel", ["chan_arm_kernel", "chan_arb_kernel"])
 @pytest.mark.parametrize("rate,taps", [(0.3, None), (0.7, None), (0.13, None), (0.9999, None), (0.4, None), (2.0 / 3, None), (1.0 / 7, None),
-                                       (1.5, "own"), (2.75, "own"), (1.0, "own")])
-def test_lds_bank_kernel_is_bit_exact(rate, taps, g):
-    """chan_arb_kernel (filter banks in LDS) keeps the reference's summation order: bit-identical to the oracle's
-    float evaluation, for fractional rates (interpolating between arms; 1/7 is one as a float: 32/rate = 223.99998)
-    and for rates that step through the arms without interpolating (0.4, 2/3: d_flt_rate 0, d_dec_rate 80, 48)."""
+                                       (0.37, None), (1.5, "own"), (2.75, "own"), (1.0, "own")])
+def test_arm_and_lds_bank_kernels_are_bit_exact(rate, taps, kernel, g, monkeypatch):
+    """chan_arm_kernel (a tile's outputs sorted by arm, taps wave-uniform) and chan_arb_kernel (filter banks in LDS, one arm
+    per lane: what the former falls back to, forced here with LORA_CHAN_NO_ARM) keep the reference's summation order:
+    bit-identical to the oracle's float evaluation, for fractional rates (interpolating between arms; 1/7 is one as a
+    float: 32/rate = 223.99998; 0.37 visits all 32 arms in every tile, 0.3 three or four) and for rates that step through
+    the arms without interpolating (0.4, 2/3: d_flt_rate 0, d_dec_rate 80, 48)."""
     if taps == "own":
         taps = (np.hamming(32 * 12 + 5) * np.sinc(np.linspace(-6, 6, 32 * 12 + 5))).astype(np.float32)
     x = noise(200_000, 31)
     ref = oracle.PfbArbResampler(rate, taps)
     want = ref.work(x)
+    if kernel == "chan_arb_kernel":
+        monkeypatch.setenv("LORA_CHAN_NO_ARM", "1")
     ch = g.channelizer(0.0, rate, ref.taps)
-    assert ch.kernel_name == "chan_arb_kernel"
+    monkeypatch.delenv("LORA_CHAN_NO_ARM", raising=False)
+    assert ch.kernel_name == kernel
     got = ch.work(x)
     assert len(got) == len(want) and np.array_equal(got, want)
     ch.reset()
@@ -279,7 +291,7 @@ def test_random_streams_follow_the_oracle(g):
         if len(want) == 0:
             ch.close()
             continue
-        if offset == 0.0 and ch.kernel_name in ("chan_general_kernel", "chan_arb_kernel"):
+        if offset == 0.0 and ch.kernel_name in ("chan_general_kernel", "chan_arb_kernel", "chan_arm_kernel"):
             assert np.array_equal(got, want), what
             exact += 1
         elif offset == 0.0:
@@ -383,7 +395,7 @@ def test_committed_golden_vectors(g):
         else:
             assert rel_max(got, want) <= 5e-5, k
         ch.close()
-    assert names == {"chan_decim_kernel", "chan_arb_kernel", "chan_general_kernel"}
+    assert names == {"chan_decim_kernel", "chan_arm_kernel", "chan_general_kernel"}
 
 
 def test_handles_are_independent_across_threads(g):
