@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip_de
 OK, EINVAL, EUNSUPPORTED, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4, -5
 NOALLOC_MAX_HANDLES = 16      # include/lora_hip_demod.h: LORA_HIP_NOALLOC_MAX_HANDLES
 WIN_UP, WIN_SFD = 0, 1
-IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED, OUT_PINNED, NO_VAL = 1, 2, 4, 8, 16, 32, 64
+IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED, OUT_PINNED, NO_VAL, LANE1 = 1, 2, 4, 8, 16, 32, 64, 128
 
 WIN_DESC_DTYPE = np.dtype([("pos", "<u8"), ("chirp_off", "<u2"), ("kind", "u1"), ("reserved", "u1", (5,))])
 assert WIN_DESC_DTYPE.itemsize == 16
@@ -28,7 +28,7 @@ assert WIN_RUN_DTYPE.itemsize == 24
 EXPORTS = (
     "lora_hip_strerror", "lora_hip_last_hip_error", "lora_hip_make_chirp_tables", "lora_hip_make_kaiser",
     "lora_hip_demod_create", "lora_hip_demod_destroy", "lora_hip_demod_set_stream", "lora_hip_demod_batch",
-    "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_batch_runs",
+    "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_batch_runs", "lora_hip_demod_sync",
     "lora_hip_host_alloc", "lora_hip_host_free", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
     "lora_hip_demod_kernel_name", "lora_hip_demod_stage_iq", "lora_hip_demod_stage_iq2",
     "lora_hip_demod_stage_iq2_dev", "lora_hip_demod_fetch", "lora_demod_core_work_device", "lora_demod_core_set_stream",
@@ -108,6 +108,7 @@ def lib():
     L.lora_demod_core_set_collect.argtypes = [vp, i]; L.lora_demod_core_set_collect.restype = i
     L.lora_demod_core_collected.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.lora_demod_core_collected.restype = i
     L.lora_hip_demod_batch_runs.argtypes = [vp, vp, sz, vp, sz, vp, vp, u]; L.lora_hip_demod_batch_runs.restype = i
+    L.lora_hip_demod_sync.argtypes = [vp, i]; L.lora_hip_demod_sync.restype = i
     L.lora_hip_host_alloc.argtypes = [C.POINTER(vp), sz]; L.lora_hip_host_alloc.restype = i
     L.lora_hip_host_free.argtypes = [vp]; L.lora_hip_host_free.restype = None
     for nme in ("lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches",

@@ -104,6 +104,7 @@ struct Pin {
 struct Plan {
   bool active = false;
   uint64_t a_start = 0; size_t a_count = 0;          // window j of A starts at a_start + j*N/16
+  uint64_t walk_end = 0;                             // the state machine runs on this plan while its read index is <= walk_end
   Pin<uint16_t> a_idx; Pin<float> a_val;
   std::vector<PRun> sfd[OVERLAP_FACTOR]; size_t sfd_cur[OVERLAP_FACTOR] = {0};
   Pin<uint16_t> s_idx;
@@ -170,7 +171,15 @@ struct lora_demod_core : WalkState {
   size_t total() const { return buf.size() + cur_n; }
   uint64_t base = 0;
   // planned evaluation (Plan above): mode 0 off, 1 when the input is long enough to pay for it, 2 always
-  Plan plan; int plan_mode = 1;
+  // Three plans: a long input is planned in stretches, and while the state machine walks one stretch (`planp`) the GPU
+  // already evaluates the SFD stage of the next and the lattice sweep of the one after (pipeline_run)
+  Plan plans[3]; Plan *planp = &plans[0]; int plan_mode = 1;
+  Plan &cur() { return *planp; }
+  unsigned walk_lane = 0;        // LORA_HIP_LANE1 while stretches are in flight: what the walk launches must not queue behind them
+  // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs about 0.07 ms of launches,
+  // synchronisations and the READ stage's round trip; measured on 524 k positions (8.4 M samples at SF8, 386 packets,
+  // profiles/r03_pipeline.txt): 1 stretch 1.91 ms, 2 stretches 1.66, 4 stretches 1.70, 8 stretches 1.99
+  size_t stretch_min = 180000;
   bool shadow = false;           // dry run: no launches, no PDUs, misses are predicted and recorded in `needs`
   std::vector<PRun> needs;
   std::vector<uint16_t> fire;
@@ -271,7 +280,7 @@ int launch_run(lora_demod_core *c, Run &r, uint64_t start, uint64_t stride, size
                unsigned off_step, unsigned kind) {
   r.start = start; r.stride = stride; r.off0 = off0; r.off_step = off_step; r.kind = kind;
   r.idx.assign(count, 0); r.val.assign(count, 0.f);
-  const int rc = launch_strided(c, start, stride, count, off0, off_step, kind, r.idx.data(), r.val.data(), 0);
+  const int rc = launch_strided(c, start, stride, count, off0, off_step, kind, r.idx.data(), r.val.data(), c->walk_lane);
   if (rc) { r.idx.clear(); r.val.clear(); }
   return rc;
 }
@@ -292,7 +301,6 @@ constexpr int kShadowStop = 1;                    // dry run met something it ca
 // lattice windows; on demand a packet costs two to four launches.  Measured on configs[3] (one packet per 280-symbol
 // capture, four blocks in flight): 0.19 s planned against 0.12 s on demand, so the plan starts where several packets fit.
 constexpr size_t kPlanMinSymbols = 1024;
-constexpr size_t kPlanChunk = (size_t)1 << 22;    // lattice positions per plan (a longer input is planned in stretches)
 constexpr size_t kPlanMaxSfd = (size_t)1 << 23;   // SFD windows per plan
 constexpr unsigned kMaxReplans = 16;
 constexpr unsigned kSfdSpan = 9 * OVERLAP_FACTOR + 1;   // :283-292: nine full calls, then the call that gives up evaluates one
@@ -317,7 +325,8 @@ void push_planned(lora_demod_core *c, std::vector<PRun> &list, PRun r) {
 }
 
 // all sweeps of `runs` in one launch (two with a device-resident input when some windows start inside the carry)
-int launch_planned(lora_demod_core *c, std::vector<PRun *> &runs, unsigned kind, Pin<uint16_t> &idx, Pin<float> *val) {
+int launch_planned(lora_demod_core *c, std::vector<PRun *> &runs, unsigned kind, Pin<uint16_t> &idx, Pin<float> *val,
+                   unsigned xflags = 0) {
   if (runs.empty()) return LORA_HIP_OK;
   int rc = ensure_staged(c);
   if (rc) return rc;
@@ -343,7 +352,7 @@ int launch_planned(lora_demod_core *c, std::vector<PRun *> &runs, unsigned kind,
   const size_t total = n_early + n_late;
   if ((rc = idx.ensure(total))) return fail(c, rc, "host_alloc");
   if (val && (rc = val->ensure(total))) return fail(c, rc, "host_alloc");
-  const unsigned flags = LORA_HIP_OUT_PINNED | (val ? 0u : (unsigned)LORA_HIP_NO_VAL);
+  const unsigned flags = LORA_HIP_OUT_PINNED | (val ? 0u : (unsigned)LORA_HIP_NO_VAL) | xflags;
   if (n_early) {
     rc = lora_hip_demod_batch_runs(c->hip, nullptr, split ? carry + c->head_n : c->total(), early.data(), early.size(),
                                    idx.p, val ? val->p : nullptr, flags | LORA_HIP_IQ_STAGED);
@@ -385,8 +394,7 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
 
 // SFD stage: behind every lattice position of A at which the preamble rule holds (:247-273: the newest four windows of
 // one phase within +-1 of the newest, not squelched), the windows one sync attempt entered there can evaluate
-int plan_sfd(lora_demod_core *c) {
-  Plan &P = c->plan;
+int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
   const double t0 = now_s();
   const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
   const uint16_t *ai = P.a_idx.p; const float *av = P.a_val.p;
@@ -453,7 +461,7 @@ int plan_sfd(lora_demod_core *c) {
     P.sfd_cur[ph] = 0;
   }
   const double t1 = now_s();
-  const int rc = launch_planned(c, all, LORA_WIN_SFD, P.s_idx, nullptr);
+  const int rc = launch_planned(c, all, LORA_WIN_SFD, P.s_idx, nullptr, xflags);
   c->t_stage[1] += t1 - t0; c->t_stage[2] += now_s() - t1;
   return rc;
 }
@@ -461,8 +469,8 @@ int plan_sfd(lora_demod_core *c) {
 // READ stage: a dry run of the state machine from its present state over what is known (A, the SFD sweeps, every
 // cached result); the header/payload windows it asks for are recorded and then evaluated in one launch
 int plan_reads(lora_demod_core *c) {
-  Plan &P = c->plan;
-  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  Plan &P = c->cur();
+  const unsigned n = c->d_num_symbols;
   P.rd.clear(); P.rd_cur = 0; c->needs.clear();
   const double t0 = now_s();
   const WalkState saved = *c;
@@ -472,7 +480,7 @@ int plan_reads(lora_demod_core *c) {
   const size_t saved_last_up = c->last_up;
   c->shadow = true;
   const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
-  const uint64_t a_last = P.a_start + (uint64_t)(P.a_count - 1) * step;
+  const uint64_t a_last = P.walk_end;
   int rc = LORA_HIP_OK;
   try {
     while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
@@ -498,7 +506,7 @@ int plan_reads(lora_demod_core *c) {
   std::vector<PRun *> all;
   for (PRun &r : P.rd) all.push_back(&r);
   const double t1 = now_s();
-  const int rl = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val);
+  const int rl = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane);
   c->t_stage[3] += t1 - t0; c->t_stage[4] += now_s() - t1;
   return rl;
 }
@@ -523,8 +531,8 @@ void trim_idle(lora_demod_core *c) {
 // (which clears all state, :215-229) and runs for real from there, so that its final state never rests on a prediction.
 // A decision that does not hold puts it back at the S_RESET call before that packet instead.
 int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
-  Plan &P = c->plan;
-  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR, F = c->d_fft_size_factor;
+  Plan &P = c->cur();
+  const unsigned n = c->d_num_symbols, F = c->d_fft_size_factor;
   P.rd.clear(); P.rd_cur = 0; c->needs.clear();
   c->patches.clear(); c->snaps.clear(); c->pdu_syms.clear(); c->pdu_off.clear();
   const double t0 = now_s();
@@ -532,7 +540,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   const uint64_t saved_calls = c->n_calls;
   c->shadow = true; c->deferred = true;
   const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
-  const uint64_t a_last = P.a_start + (uint64_t)(P.a_count - 1) * step;
+  const uint64_t a_last = P.walk_end;
   int rc = LORA_HIP_OK;
   try {
     while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
@@ -559,7 +567,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   std::vector<PRun *> all;
   for (PRun &r : P.rd) all.push_back(&r);
   const double t1 = now_s();
-  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val);
+  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane);
   const double t2 = now_s();
   c->t_stage[3] += t1 - t0; c->t_stage[4] += t2 - t1;
   for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd_cur[ph] = 0;     // the read index goes back
@@ -612,34 +620,27 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   return LORA_HIP_OK;
 }
 
-// Start a plan at the read index (see struct Plan).  Leaves the plan inactive when the input is too short to pay.
-int plan_begin(lora_demod_core *c, lora_pdu_cb cb, void *user) {
-  Plan &P = c->plan;
+// Lattice sweep of one stretch into plan P: every lattice position from a_start on, all 16 phases, chirp offset 0.  Results
+// handed in through lora_demod_core_preload (time sharding: other GPUs swept the lattice) are used as they are.  The sweep is
+// only queued (xflags carries LORA_HIP_ASYNC): its results are in P's page-locked arrays once lane 0 has been synchronised.
+int stage_lattice(lora_demod_core *c, Plan &P, uint64_t a_start, size_t count, uint64_t walk_end, unsigned xflags) {
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  int rc;
   P.active = false; P.replans = 0;
   for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) { P.sfd[ph].clear(); P.sfd_cur[ph] = 0; }
   P.rd.clear(); P.rd_cur = 0;
-  if (c->plan_mode == 0) return LORA_HIP_OK;
-  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
-  const uint64_t end = c->base + c->total();
-  const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
-  if (end < c->pos + need) return LORA_HIP_OK;
-  size_t count = (size_t)((end - c->pos - n) / step + 1);
-  if (c->plan_mode == 1 && count < kPlanMinSymbols * OVERLAP_FACTOR) return LORA_HIP_OK;
-  if (count > kPlanChunk) count = kPlanChunk;
-  int rc;
   if ((rc = P.a_idx.ensure(count)) || (rc = P.a_val.ensure(count))) return fail(c, rc, "host_alloc");
-  // results handed in through lora_demod_core_preload (time sharding: other GPUs swept the lattice) are used as they are
   bool have = false;
   if (!c->pre_runs.empty()) {
     memset(P.a_idx.p, 0xFF, count * sizeof(uint16_t));     // 0xFFFF is no bin: N*F < 65536
     for (const Run &r : c->pre_runs) {
       if (r.stride != n || r.off0 != 0 || r.off_step != 0 || r.kind != LORA_WIN_UP || (r.start % step)) continue;
       size_t k = 0;
-      if (r.start < c->pos) k = (size_t)((c->pos - r.start + n - 1) / n);
+      if (r.start < a_start) k = (size_t)((a_start - r.start + n - 1) / n);
       for (; k < r.idx.size(); k++) {
         const uint64_t p = r.start + (uint64_t)k * n;
-        if ((p - c->pos) % step) break;
-        const uint64_t j = (p - c->pos) / step;
+        if ((p - a_start) % step) break;
+        const uint64_t j = (p - a_start) / step;
         if (j >= count) break;
         P.a_idx.p[j] = r.idx[k]; P.a_val.p[j] = r.val[k];
       }
@@ -648,20 +649,95 @@ int plan_begin(lora_demod_core *c, lora_pdu_cb cb, void *user) {
     for (size_t j = 0; j < count; j++) if (P.a_idx.p[j] == 0xFFFF) { have = false; break; }
   }
   const double t0 = now_s();
-  if (!have && (rc = launch_strided(c, c->pos, step, count, 0, 0, LORA_WIN_UP, P.a_idx.p, P.a_val.p, LORA_HIP_OUT_PINNED))) return rc;
+  if (!have && (rc = launch_strided(c, a_start, step, count, 0, 0, LORA_WIN_UP, P.a_idx.p, P.a_val.p, LORA_HIP_OUT_PINNED | xflags))) return rc;
   c->t_stage[0] += now_s() - t0;
-  P.a_start = c->pos; P.a_count = count; P.active = true;
+  P.a_start = a_start; P.a_count = count; P.walk_end = walk_end;
   c->n_plans++;
-  if ((rc = plan_sfd(c))) { P.active = false; return rc; }
-  if ((rc = plan_walk(c, cb, user))) { P.active = false; return rc; }
   return LORA_HIP_OK;
+}
+
+// Planned evaluation of one work() call (see struct Plan), in stretches that overlap in time.  The host's part of a plan --
+// the preamble rule over the lattice results, the first pass of the state machine, the check of its predictions -- is
+// strictly serial and as long as the GPU's part, so one plan for the whole input left each side idle half the time.  The
+// input is therefore cut into stretches of the lattice; per iteration k the host
+//     waits for lane 0 (lattice sweep of stretch k, SFD stage of stretch k-1),
+//     queues the lattice sweep of stretch k+1,
+//     evaluates the preamble rule of stretch k and queues its SFD stage,
+//     walks stretch k-1: first pass, READ stage (lane 1, so that it does not queue behind the sweeps), check, real run,
+// and the GPU works on stretches k and k+1 while the state machine is on k-1.  Stretches overlap by kStretchOverlap lattice
+// positions and the state machine changes plans in the middle of the overlap: far enough into the next stretch for the
+// preamble rule's three windows of history and for a sync attempt still in progress (at most 10 calls, :283-292) to have
+// been entered inside it.  What a plan holds for a window is exact whichever stretch evaluated it, and whatever no plan
+// holds is evaluated on demand, so the cut changes which launch evaluates a window, never a result.
+constexpr size_t kStretchMax = (size_t)1 << 21;
+constexpr unsigned kMaxStretches = 8;
+constexpr size_t kStretchOverlap = 1024;              // 64 symbols
+int pipeline_run(lora_demod_core *c, lora_pdu_cb cb, void *user) {
+  for (Plan &P : c->plans) P.active = false;
+  c->planp = &c->plans[0]; c->walk_lane = 0;
+  if (c->plan_mode == 0) return LORA_HIP_OK;
+  const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
+  const uint64_t end = c->base + c->total();
+  const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
+  if (end < c->pos + need) return LORA_HIP_OK;
+  const size_t total = (size_t)((end - c->pos - n) / step + 1);
+  if (c->plan_mode == 1 && total < kPlanMinSymbols * OVERLAP_FACTOR) return LORA_HIP_OK;
+  size_t K = total / c->stretch_min;
+  if (K < 1) K = 1;
+  if (K > kMaxStretches) K = kMaxStretches;
+  size_t S = (total + K - 1) / K;
+  if (S > kStretchMax) { S = kStretchMax; K = (total + S - 1) / S; }
+  S = (S + OVERLAP_FACTOR - 1) / OVERLAP_FACTOR * OVERLAP_FACTOR;
+  const uint64_t p0 = c->pos;
+  const uint64_t last = p0 + (uint64_t)(total - 1) * step;          // last lattice position at which a window fits
+  auto a_start = [&](size_t k) { return p0 + (uint64_t)(k ? k * S - kStretchOverlap : 0) * step; };
+  auto a_last = [&](size_t k) { const uint64_t e = p0 + (uint64_t)((k + 1) * S - 1) * step; return (k + 1 == K || e > last) ? last : e; };
+  auto walk_end = [&](size_t k) { return k + 1 == K ? a_last(k) : a_last(k) - (uint64_t)(kStretchOverlap / 2) * step; };
+  auto issue_lattice = [&](size_t k) {
+    return stage_lattice(c, c->plans[k % 3], a_start(k), (size_t)((a_last(k) - a_start(k)) / step + 1), walk_end(k),
+                         K > 1 ? (unsigned)LORA_HIP_ASYNC : 0u);
+  };
+  const unsigned async = K > 1 ? (unsigned)LORA_HIP_ASYNC : 0u;
+  c->walk_lane = K > 1 ? (unsigned)LORA_HIP_LANE1 : 0u;
+  int rc = issue_lattice(0);
+  for (size_t k = 0; !rc && k <= K; k++) {
+    if (async && (rc = lora_hip_demod_sync(c->hip, 0))) { rc = fail(c, rc, "sync"); break; }
+    if (k + 1 < K && (rc = issue_lattice(k + 1))) break;
+    if (k < K) {
+      Plan &Q = c->plans[k % 3];
+      Q.active = true;                                   // plan_sfd reads its lattice results
+      rc = plan_sfd(c, Q, async);
+      Q.active = false;
+      if (rc) break;
+    }
+    if (k >= 1) {
+      c->planp = &c->plans[(k - 1) % 3];
+      Plan &P = c->cur();
+      P.active = true;
+      if (c->pos > P.walk_end) { P.active = false; continue; }      // the state machine is already past this stretch (a long SFD skip)
+      if ((rc = plan_walk(c, cb, user))) break;
+      if (k == K) break;                                 // the last stretch: the caller's loop runs it to the end of the input
+      while (c->base + c->total() >= c->pos + need && c->pos <= P.walk_end) {
+        unsigned consumed = 0;
+        if ((rc = general_work(c, cb, user, &consumed))) break;
+        c->pos += consumed;
+      }
+      P.active = false;
+    }
+  }
+  if (rc) {
+    (void)lora_hip_demod_sync(c->hip, 0);              // nothing may still write a plan's arrays when the caller sees the error
+    for (Plan &P : c->plans) P.active = false;
+  }
+  c->walk_lane = 0;
+  return rc;
 }
 
 // (argmax, max) of the up path at (pos, off): lib/demod_impl.cc:177-206
 int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, float *val) {
   const unsigned n = c->d_num_symbols;
   size_t k;
-  Plan &P = c->plan;
+  Plan &P = c->cur();
   if (P.active) {
     if (off == 0 && plan_a_find(P, pos, n / OVERLAP_FACTOR, &k)) { *idx = P.a_idx.p[k]; *val = P.a_val.p[k]; return LORA_HIP_OK; }
     if (planned_find(P.rd, P.rd_cur, pos, off, n, &k)) { *idx = P.r_idx.p[k]; *val = P.r_val.p[k]; return LORA_HIP_OK; }
@@ -739,13 +815,13 @@ int get_up(lora_demod_core *c, uint64_t pos, unsigned off, unsigned short *idx, 
 int get_sfd(lora_demod_core *c, uint64_t call_pos, unsigned off, unsigned short *idx, const uint16_t **seq, size_t *seq_n) {
   const unsigned n = c->d_num_symbols, step = n / OVERLAP_FACTOR;
   size_t k;
-  if (c->plan.active) {
+  if (c->cur().active) {
     const unsigned ph = (unsigned)((call_pos & (n - 1)) / step);
     size_t rem = 0;
-    if (planned_find(c->plan.sfd[ph], c->plan.sfd_cur[ph], call_pos + off, off, n, &k, &rem)) {
-      *idx = c->plan.s_idx.p[k];
+    if (planned_find(c->cur().sfd[ph], c->cur().sfd_cur[ph], call_pos + off, off, n, &k, &rem)) {
+      *idx = c->cur().s_idx.p[k];
       // the windows of one call lie N/16 apart with offsets N/16 apart: the same sweep holds the next ones in order
-      if (seq) { *seq = c->plan.s_idx.p + k; *seq_n = rem; }
+      if (seq) { *seq = c->cur().s_idx.p + k; *seq_n = rem; }
       return LORA_HIP_OK;
     }
   }
@@ -933,6 +1009,7 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   if (rc) { delete c; return rc; }
   if (const char *e = getenv("LORA_CORE_FAULT")) c->fault_at = atol(e);
   if (const char *e = getenv("LORA_CORE_TIMING")) c->timing = atoi(e) != 0;
+  if (const char *e = getenv("LORA_CORE_STRETCH")) { const long v = atol(e); if (v >= 4096) c->stretch_min = (size_t)v; }
   if (const char *e = getenv("LORA_CORE_PLAN")) { const int m = atoi(e); if (m >= 0 && m <= 2) c->plan_mode = m; }
   c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor;
   c->d_num_symbols = 1u << sf;                                      // :79
@@ -962,7 +1039,8 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->staged = false;
   c->n_calls = 0; c->n_windows = 0; c->n_launches = 0;
   c->n_plans = 0; c->n_replans = 0; c->n_demand = 0;
-  c->plan.active = false; c->shadow = false; c->deferred = false;
+  for (Plan &P : c->plans) P.active = false;
+  c->planp = &c->plans[0]; c->shadow = false; c->deferred = false;
   c->n_pred = 0; c->n_rollbacks = 0;
   c->err.clear();
   return LORA_HIP_OK;
@@ -1015,13 +1093,9 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   for (double &t : c->t_stage) t = 0;
   c->t_cb = 0;
   const double t_begin = now_s();
-  try { rc = plan_begin(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
+  try { rc = pipeline_run(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   const double t_walk = now_s();
   while (!rc && c->base + c->total() >= c->pos + need) {
-    if (c->plan.active && c->pos > c->plan.a_start + (uint64_t)(c->plan.a_count - 1) * (c->d_num_symbols / OVERLAP_FACTOR)) {
-      try { rc = plan_begin(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }   // next stretch of a long input
-      if (rc) break;
-    }
     unsigned consumed = 0;
     rc = general_work(c, cb, user, &consumed);
     if (rc) break;
@@ -1065,7 +1139,8 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   c->base = c->pos > c->base ? c->pos : c->base;
   c->cur_in = nullptr; c->cur_n = 0; c->cur_dev = false; c->head_n = 0;
   c->staged = false;
-  c->plan.active = false;           // planned results describe this call's samples
+  for (Plan &P : c->plans) P.active = false;      // planned results describe this call's samples
+  c->planp = &c->plans[0];
   if (rc) return rc;
   return LORA_HIP_OK;
 }

@@ -44,6 +44,18 @@ struct lora_hip_demod {
   unsigned char *d_out = nullptr, *h_out = nullptr; size_t cap_out = 0;
   unsigned *d_ticket = nullptr;          // window-group ticket counters of the persistent kernel (the allocating entry points)
   bool ticket_dirty = false;             // a launch on d_ticket may have failed: clear those counters before the next
+  // Second lane (flag LORA_HIP_LANE1): a stream of the handle's own with its own counters, result staging, descriptor
+  // and run buffers, so that a small launch (a block's header/payload windows) can overtake the long sweeps queued on the
+  // first lane instead of waiting behind them.  Launches on the two lanes may overlap in time; launches on one lane are ordered.
+  hipStream_t aux_stream = nullptr;
+  unsigned *d_ticket1 = nullptr; bool ticket1_dirty = false;
+  void *d_desc1 = nullptr; size_t cap_desc1 = 0;
+  unsigned char *d_runs1 = nullptr; size_t cap_runs1 = 0;
+  unsigned char *d_out1 = nullptr, *h_out1 = nullptr; size_t cap_out1 = 0;
+  // run lists of lora_hip_demod_batch_runs: page-locked staging per lane, copied to HBM behind the call (no synchronisation);
+  // the event says when the lane's last copy is done with it
+  unsigned char *h_runs[2] = {nullptr, nullptr}; size_t cap_hruns[2] = {0, 0};
+  hipEvent_t runs_done[2] = {nullptr, nullptr}; bool runs_pending[2] = {false, false};
   int scratch_slot = -1;                 // this handle's slot of the per-device `scratch` (-1: all were taken at create)
   bool scratch_dirty = false;            // the same for the handle's scratch slot (each buffer has its own flag)
   long fault_at = -1, n_launch = 0;      // LORA_HIP_FAULT=n: test hook, the n-th launch on the handle fails and leaves its counters undefined
@@ -65,7 +77,7 @@ unsigned g_scratch_stale[kMaxDevices] = {0};        // bit s: slot s was given b
 int hip_fail(lora_hip_demod *h, hipError_t e, const char *what) {
   // any HIP failure on the handle may have been a launch that died half way: both counter buffers are suspect, and each
   // is cleared (and its own flag reset) by the next launch that uses it
-  if (h) { snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e)); h->ticket_dirty = true; h->scratch_dirty = true; }
+  if (h) { snprintf(h->hip_err, sizeof h->hip_err, "%s: %s", what, hipGetErrorString(e)); h->ticket_dirty = true; h->ticket1_dirty = true; h->scratch_dirty = true; }
   return LORA_HIP_EHIP;
 }
 #define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
@@ -163,10 +175,12 @@ bool pick_variant(unsigned sf, unsigned f, Variant *v) {
   }
 }
 
-// own_ticket: the counters are the handle's d_ticket (allocating entry points); otherwise the handle's scratch slot
-int launch(lora_hip_demod *h, KParams &p, const bool own_ticket) {
-  unsigned *const ticket = own_ticket ? h->d_ticket : g_scratch_ptr[h->device] + (size_t)h->scratch_slot * kScratchWords;
-  bool &dirty = own_ticket ? h->ticket_dirty : h->scratch_dirty;
+// own_ticket: the counters are the handle's (d_ticket on lane 0, d_ticket1 on lane 1; the allocating entry points);
+// otherwise the handle's scratch slot (lane 0 only)
+int launch(lora_hip_demod *h, KParams &p, const bool own_ticket, const int lane = 0) {
+  unsigned *const ticket = !own_ticket ? g_scratch_ptr[h->device] + (size_t)h->scratch_slot * kScratchWords : (lane ? h->d_ticket1 : h->d_ticket);
+  bool &dirty = !own_ticket ? h->scratch_dirty : (lane ? h->ticket1_dirty : h->ticket_dirty);
+  const hipStream_t stream = lane ? h->aux_stream : h->stream;
 #if LORA_CLOCK || LORA_STAMPS
   if (!own_ticket) {   // the diagnostic builds allocate and synchronise in here: not what the no-allocation entry point promises
     snprintf(h->hip_err, sizeof h->hip_err, "lora_hip_demod_batch_strided_noalloc is not available in LORA_CLOCK / LORA_STAMPS builds");
@@ -211,17 +225,17 @@ int launch(lora_hip_demod *h, KParams &p, const bool own_ticket) {
   // library's __device__ array starts as zeros) and after every launch that ran to its end: the kernel's last workgroup
   // clears them.  A launch that failed leaves them undefined, so the next one clears them itself.
   if (dirty) {
-    hipError_t em = hipMemsetAsync(ticket, 0, kScratchWords * sizeof(unsigned), h->stream);
+    hipError_t em = hipMemsetAsync(ticket, 0, kScratchWords * sizeof(unsigned), stream);
     if (em != hipSuccess) return hip_fail(h, em, "hipMemsetAsync");
     dirty = false;
   }
   if (h->fault_at > 0 && ++h->n_launch == h->fault_at) {   // test hook: what a launch that died half way leaves behind
-    (void)hipMemsetAsync(ticket, 0xA5, kScratchWords * sizeof(unsigned), h->stream);
+    (void)hipMemsetAsync(ticket, 0xA5, kScratchWords * sizeof(unsigned), stream);
     return hip_fail(h, hipErrorLaunchFailure, "kernel launch (LORA_HIP_FAULT test hook)");
   }
   p.ticket = ticket;
   p.twist = h->d_twist; p.fr = h->fft_factor;
-  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), lds, h->stream, p);
+  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), lds, stream, p);
 #if LORA_STAMPS
   {
     std::vector<unsigned long long> hd(ndbg);
@@ -395,6 +409,11 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_ticket, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemset(h->d_ticket, 0, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(LORA_HIP_EHIP);
+  if (hipMalloc((void **)&h->d_ticket1, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
+  if (hipMemset(h->d_ticket1, 0, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_EHIP);
+  for (int l = 0; l < 2; l++)
+    if (hipEventCreateWithFlags(&h->runs_done[l], hipEventDisableTiming) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
@@ -447,6 +466,13 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  for (int l = 0; l < 2; l++) {
+    if (h->runs_done[l]) (void)hipEventDestroy(h->runs_done[l]);
+    if (h->h_runs[l]) (void)hipHostFree(h->h_runs[l]);
+  }
+  (void)hipFree(h->d_ticket1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_runs1); (void)hipFree(h->d_out1);
+  if (h->h_out1) (void)hipHostFree(h->h_out1);
   if (h->scratch_slot >= 0 && h->device < kMaxDevices) {   // the slot goes back; the next owner clears it if this one left it undefined
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     g_scratch_used[h->device] &= ~(1u << h->scratch_slot);
@@ -522,11 +548,22 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   if (n_win > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
   const bool iq_dev = flags & LORA_HIP_IQ_ON_DEVICE, out_dev = flags & LORA_HIP_OUT_ON_DEVICE;
   const bool desc_dev = flags & LORA_HIP_DESC_ON_DEVICE;
-  if ((flags & LORA_HIP_ASYNC) && ((!iq_dev && !iq_staged) || !out_dev || (desc && !desc_dev))) return LORA_HIP_EINVAL;
+  const bool out_pinned = (flags & LORA_HIP_OUT_PINNED) && !out_dev;
+  // without a synchronisation the caller's buffers must be such that the copies can run behind the call's return:
+  // device memory, or page-locked host memory for the results
+  if ((flags & LORA_HIP_ASYNC) && ((!iq_dev && !iq_staged) || (!out_dev && !out_pinned) || (desc && !desc_dev))) return LORA_HIP_EINVAL;
+  const int lane = (flags & LORA_HIP_LANE1) ? 1 : 0;
+  if (lane && !iq_dev && !iq_staged) return LORA_HIP_EINVAL;           // the staging copy belongs to lane 0's stream
   if (n_win == 0) return LORA_HIP_OK;
   if (n_samples < h->n) return LORA_HIP_EINVAL;      // the kernel redirects bad windows to sample 0
   DeviceGuard guard(h->device);
   HIP_TRY(h, guard.err);
+  const hipStream_t stream = lane ? h->aux_stream : h->stream;
+  void *&d_desc = lane ? h->d_desc1 : h->d_desc;
+  size_t &cap_desc = lane ? h->cap_desc1 : h->cap_desc;
+  unsigned char *&d_out = lane ? h->d_out1 : h->d_out;
+  unsigned char *&h_out = lane ? h->h_out1 : h->h_out;
+  size_t &cap_out = lane ? h->cap_out1 : h->cap_out;
   int rc;
   // inputs
   if (iq_dev) p.iq = reinterpret_cast<const float2 *>(iq);
@@ -534,7 +571,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   else {
     h->staged_n = 0;
     if ((rc = grow(h, &h->d_iq, &h->cap_iq, n_samples)) != LORA_HIP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_iq, iq, n_samples * sizeof(float2), hipMemcpyHostToDevice, stream));
     p.iq = h->d_iq;
   }
   p.n_samples = n_samples;
@@ -547,48 +584,51 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
         if (desc[i].pos > n_samples || n_samples - desc[i].pos < h->n) return LORA_HIP_EINVAL;
       }
       size_t bytes = n_win * sizeof(lora_win_desc);
-      if ((rc = grow(h, reinterpret_cast<unsigned char **>(&h->d_desc), &h->cap_desc, bytes)) != LORA_HIP_OK) return rc;
-      HIP_TRY(h, hipMemcpyAsync(h->d_desc, desc, bytes, hipMemcpyHostToDevice, h->stream));
-      p.desc = h->d_desc;
+      if ((rc = grow(h, reinterpret_cast<unsigned char **>(&d_desc), &cap_desc, bytes)) != LORA_HIP_OK) return rc;
+      HIP_TRY(h, hipMemcpyAsync(d_desc, desc, bytes, hipMemcpyHostToDevice, stream));
+      p.desc = d_desc;
     }
   } else p.desc = nullptr;
   // outputs
   if (out_dev) { p.out_idx = max_idx; p.out_val = max_val; }
   else {
-    if (n_win > h->cap_out) {
+    if (n_win > cap_out) {
+      // (hipFree waits for the device: a launch still reading the old block on this lane is done before it goes)
       const size_t ncap = n_win + n_win / 4 + 64;
-      if (h->d_out) { (void)hipFree(h->d_out); h->d_out = nullptr; }
-      if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
-      h->cap_out = 0;
-      hipError_t e = hipMalloc((void **)&h->d_out, ncap * 6);
-      if (e != hipSuccess) { h->d_out = nullptr; hip_fail(h, e, "hipMalloc"); return LORA_HIP_ENOMEM; }
-      e = hipHostMalloc((void **)&h->h_out, ncap * 6, hipHostMallocDefault);
-      if (e != hipSuccess) { h->h_out = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
-      h->cap_out = ncap;
+      if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
+      if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
+      cap_out = 0;
+      hipError_t e = hipMalloc((void **)&d_out, ncap * 6);
+      if (e != hipSuccess) { d_out = nullptr; hip_fail(h, e, "hipMalloc"); return LORA_HIP_ENOMEM; }
+      e = hipHostMalloc((void **)&h_out, ncap * 6, hipHostMallocDefault);
+      if (e != hipSuccess) { h_out = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+      cap_out = ncap;
     }
-    p.out_val = reinterpret_cast<float *>(h->d_out);
-    p.out_idx = reinterpret_cast<unsigned short *>(h->d_out + n_win * 4);     // packed behind this call's values
+    p.out_val = reinterpret_cast<float *>(d_out);
+    p.out_idx = reinterpret_cast<unsigned short *>(d_out + n_win * 4);     // packed behind this call's values
   }
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
-  if ((rc = launch(h, p, true)) != LORA_HIP_OK) return rc;
+  if ((rc = launch(h, p, true, lane)) != LORA_HIP_OK) return rc;
   if (!out_dev) {
     const size_t idx_off = n_win * 4;
-    if (flags & LORA_HIP_OUT_PINNED) {
-      if (!no_val) HIP_TRY(h, hipMemcpyAsync(max_val, h->d_out, n_win * 4, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(h, hipMemcpyAsync(max_idx, h->d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_pinned) {
+      // (an asynchronous call leaves the lane's device block busy until these copies have run: calls on one lane are
+      // ordered, so the next launch on it writes the block only behind them)
+      if (!no_val) HIP_TRY(h, hipMemcpyAsync(max_val, d_out, n_win * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(h, hipMemcpyAsync(max_idx, d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, stream));
+      if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(stream));
       return LORA_HIP_OK;
     }
-    if (no_val) HIP_TRY(h, hipMemcpyAsync(h->h_out + idx_off, h->d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, h->stream));
-    else HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, n_win * 6, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (!no_val) memcpy(max_val, h->h_out, n_win * 4);
-    memcpy(max_idx, h->h_out + idx_off, n_win * 2);
+    if (no_val) HIP_TRY(h, hipMemcpyAsync(h_out + idx_off, d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, stream));
+    else HIP_TRY(h, hipMemcpyAsync(h_out, d_out, n_win * 6, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    if (!no_val) memcpy(max_val, h_out, n_win * 4);
+    memcpy(max_idx, h_out + idx_off, n_win * 2);
     return LORA_HIP_OK;
   }
-  if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(stream));
   return LORA_HIP_OK;
 }
 
@@ -620,40 +660,64 @@ int lora_hip_demod_batch_strided(lora_hip_demod_t *h, const lora_c32 *iq, size_t
 int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, const lora_win_run *runs,
                               size_t n_runs, uint16_t *max_idx, float *max_val, unsigned flags) {
   if (!h || (n_runs && !runs)) return LORA_HIP_EINVAL;
-  if (flags & (LORA_HIP_DESC_ON_DEVICE | LORA_HIP_ASYNC)) return LORA_HIP_EINVAL;   // the run list is host memory
+  if (flags & LORA_HIP_DESC_ON_DEVICE) return LORA_HIP_EINVAL;   // the run list is host memory
   if (n_runs > 0x7FFFFFFFull) return LORA_HIP_EINVAL;
-  std::vector<RunDev> rd;
-  uint64_t total = 0;
-  try {
-    rd.reserve(n_runs);
-    for (size_t r = 0; r < n_runs; r++) {
-      const lora_win_run &u = runs[r];
-      if (u.kind > LORA_WIN_SFD || u.chirp_off >= h->n || u.chirp_off_step >= h->n) return LORA_HIP_EINVAL;
-      if (u.count == 0) continue;
-      if (u.pos0 > n_samples || n_samples - u.pos0 < h->n) return LORA_HIP_EINVAL;
-      if (u.count > 1 && u.stride != 0 && (uint64_t)(u.count - 1) > (n_samples - u.pos0 - h->n) / u.stride) return LORA_HIP_EINVAL;
-      rd.push_back(RunDev{u.pos0, u.stride, (unsigned)total, u.chirp_off, u.chirp_off_step, u.kind});
-      total += u.count;
-      if (total > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
-    }
-  } catch (const std::bad_alloc &) { return LORA_HIP_ENOMEM; }
-  if (total == 0) return LORA_HIP_OK;
+  const int lane = (flags & LORA_HIP_LANE1) ? 1 : 0;
   DeviceGuard guard(h->device);
   HIP_TRY(h, guard.err);
+  const hipStream_t stream = lane ? h->aux_stream : h->stream;
+  // The run list goes into page-locked memory of the handle and from there to HBM with an asynchronous copy (it used to be
+  // copied from a pageable vector, which cost a stream synchronisation per call).  The lane's previous copy must be done
+  // with that memory before it is overwritten.
+  if (h->runs_pending[lane]) { HIP_TRY(h, hipEventSynchronize(h->runs_done[lane])); h->runs_pending[lane] = false; }
+  if (n_runs * sizeof(RunDev) > h->cap_hruns[lane]) {
+    if (h->h_runs[lane]) { (void)hipHostFree(h->h_runs[lane]); h->h_runs[lane] = nullptr; h->cap_hruns[lane] = 0; }
+    const size_t ncap = (n_runs + n_runs / 4 + 64) * sizeof(RunDev);
+    hipError_t e = hipHostMalloc((void **)&h->h_runs[lane], ncap, hipHostMallocDefault);
+    if (e != hipSuccess) { h->h_runs[lane] = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+    h->cap_hruns[lane] = ncap;
+  }
+  RunDev *rd = reinterpret_cast<RunDev *>(h->h_runs[lane]);
+  size_t n_rd = 0;
+  uint64_t total = 0;
+  for (size_t r = 0; r < n_runs; r++) {
+    const lora_win_run &u = runs[r];
+    if (u.kind > LORA_WIN_SFD || u.chirp_off >= h->n || u.chirp_off_step >= h->n) return LORA_HIP_EINVAL;
+    if (u.count == 0) continue;
+    if (u.pos0 > n_samples || n_samples - u.pos0 < h->n) return LORA_HIP_EINVAL;
+    if (u.count > 1 && u.stride != 0 && (uint64_t)(u.count - 1) > (n_samples - u.pos0 - h->n) / u.stride) return LORA_HIP_EINVAL;
+    rd[n_rd++] = RunDev{u.pos0, u.stride, (unsigned)total, u.chirp_off, u.chirp_off_step, u.kind};
+    total += u.count;
+    if (total > 0xFFFFFFFFull / 2) return LORA_HIP_EINVAL;
+  }
+  if (total == 0) return LORA_HIP_OK;
+  void *&d_desc = lane ? h->d_desc1 : h->d_desc;
+  size_t &cap_desc = lane ? h->cap_desc1 : h->cap_desc;
+  unsigned char *&d_runs = lane ? h->d_runs1 : h->d_runs;
+  size_t &cap_runs = lane ? h->cap_runs1 : h->cap_runs;
   int rc;
-  if ((rc = grow(h, &h->d_runs, &h->cap_runs, rd.size() * sizeof(RunDev))) != LORA_HIP_OK) return rc;
-  if ((rc = grow(h, reinterpret_cast<unsigned char **>(&h->d_desc), &h->cap_desc, (size_t)total * sizeof(lora_win_desc))) != LORA_HIP_OK) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->d_runs, rd.data(), rd.size() * sizeof(RunDev), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));          // rd is pageable and goes out of scope
-  hipLaunchKernelGGL(expand_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
-                     reinterpret_cast<const RunDev *>(h->d_runs), (unsigned)rd.size(), (unsigned)total, h->n - 1,
-                     reinterpret_cast<lora_hip::WinDesc *>(h->d_desc));
+  if ((rc = grow(h, &d_runs, &cap_runs, n_rd * sizeof(RunDev))) != LORA_HIP_OK) return rc;
+  if ((rc = grow(h, reinterpret_cast<unsigned char **>(&d_desc), &cap_desc, (size_t)total * sizeof(lora_win_desc))) != LORA_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpyAsync(d_runs, rd, n_rd * sizeof(RunDev), hipMemcpyHostToDevice, stream));
+  HIP_TRY(h, hipEventRecord(h->runs_done[lane], stream));
+  h->runs_pending[lane] = true;
+  hipLaunchKernelGGL(expand_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const RunDev *>(d_runs), (unsigned)n_rd, (unsigned)total, h->n - 1,
+                     reinterpret_cast<lora_hip::WinDesc *>(d_desc));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "expand_runs launch");
   KParams p;
   memset(&p, 0, sizeof p);
-  return run_batch(h, iq, n_samples, p, reinterpret_cast<const lora_win_desc *>(h->d_desc), (size_t)total, max_idx, max_val,
+  return run_batch(h, iq, n_samples, p, reinterpret_cast<const lora_win_desc *>(d_desc), (size_t)total, max_idx, max_val,
                    flags | LORA_HIP_DESC_ON_DEVICE);
+}
+
+int lora_hip_demod_sync(lora_hip_demod_t *h, int lane) {
+  if (!h || lane < 0 || lane > 1) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  HIP_TRY(h, hipStreamSynchronize(lane ? h->aux_stream : h->stream));
+  return LORA_HIP_OK;
 }
 
 int lora_hip_host_alloc(void **p, size_t bytes) {

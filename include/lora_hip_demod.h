@@ -50,14 +50,20 @@ enum {
   LORA_HIP_IQ_ON_DEVICE = 1,    /* iq is a device pointer (HBM resident), else host memory */
   LORA_HIP_OUT_ON_DEVICE = 2,   /* max_idx / max_val are device pointers, else host memory */
   LORA_HIP_DESC_ON_DEVICE = 4,  /* desc is a device pointer */
-  LORA_HIP_ASYNC = 8,           /* do not synchronise the handle's stream before returning
-                                   (only valid when every buffer named above is on the device) */
+  LORA_HIP_ASYNC = 8,           /* do not synchronise the handle's stream before returning: valid when the samples are on
+                                   the device or staged, descriptors (if any) on the device, and the results go to device
+                                   memory or, with LORA_HIP_OUT_PINNED, to page-locked host memory, which then holds them
+                                   once the lane has been synchronised (lora_hip_demod_sync) */
   LORA_HIP_IQ_STAGED = 16,      /* iq is ignored: use the samples last given to
                                    lora_hip_demod_stage_iq (n_samples must not exceed them) */
   LORA_HIP_OUT_PINNED = 32,     /* max_idx / max_val are page-locked host memory (lora_hip_host_alloc): the results
                                    are copied straight into them instead of through the handle's own pinned mirror */
-  LORA_HIP_NO_VAL = 64          /* max_val may be NULL and is not written (host outputs only): half the copy back
+  LORA_HIP_NO_VAL = 64,         /* max_val may be NULL and is not written (host outputs only): half the copy back
                                    for callers that need the bins only, like the SFD search (demod_impl.cc:322) */
+  LORA_HIP_LANE1 = 128          /* run on the handle's second lane: a stream of the handle's own with its own counters and
+                                   staging, so that a small launch (a block's header/payload windows, :363-413) overtakes
+                                   the long sweeps queued on the first lane.  Samples must be staged or on the device.
+                                   Launches on one lane are ordered; the two lanes may overlap in time */
 };
 
 /* one symbol window: N = 2^sf samples starting at iq[pos] */
@@ -144,6 +150,11 @@ typedef struct {
 LORA_HIP_API int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples,
                                            const lora_win_run *runs, size_t n_runs,
                                            uint16_t *max_idx, float *max_val, unsigned flags);
+
+/* Wait until everything queued on a lane (0: the handle's stream or the one given to lora_hip_demod_set_stream, 1: the
+ * second lane) has run: what a caller of LORA_HIP_ASYNC calls before it reads page-locked results.  No counterpart in the
+ * reference (its general_work is synchronous, demod_impl.cc:149-450). */
+LORA_HIP_API int lora_hip_demod_sync(lora_hip_demod_t *h, int lane);
 
 /* Page-locked host memory for LORA_HIP_OUT_PINNED result buffers (hipHostMalloc / hipHostFree). */
 LORA_HIP_API int lora_hip_host_alloc(void **p, size_t bytes);

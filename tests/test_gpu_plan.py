@@ -125,6 +125,33 @@ def test_planned_block_chunked_and_device_input(sf, f, g):
         assert tr_w.tobytes() == tr_g.tobytes()
 
 
+@pytest.mark.parametrize("sf,f,snr", [(7, 2, 8), (7, 1, None), (8, 4, 3)])
+def test_planned_block_in_overlapping_stretches(sf, f, snr, g, monkeypatch):
+    """A long input is planned in stretches whose GPU stages run ahead of the state machine (pipeline_run: lattice sweep of
+    stretch k+1 and SFD stage of stretch k queued while stretch k-1 is walked, header/payload reads on the second lane).
+    The cut changes which launch evaluates a window, never a result: trace and PDUs equal the on-demand block's byte for
+    byte -- host input, device-resident input, and a chunked feed whose calls span several stretches each."""
+    import torch
+    n = 1 << sf
+    n_packets = 4 * 65536 // (16 * 45) + 60
+    cap = dense_capture(sf, n_packets, seed=4200 + sf + f, snr_db=snr, max_gap=6)
+    assert len(cap) // n > 4 * 4096
+    monkeypatch.setenv("LORA_CORE_STRETCH", "32768")   # short stretches (2048 symbols; the default is 180 000 positions): eight of them here
+    a, tr_a, st_a = run_block(g, sf, f, 0, [cap], plan=0)
+    b, tr_b, st_b = run_block(g, sf, f, 0, [cap], plan=1)
+    print(f"sf{sf} f{f}: {len(cap) // n} symbols, {len(a)} PDUs; on demand {st_a['launches']} launches; pipelined {st_b['plans']} stretches, "
+          f"{st_b['launches']} launches, {st_b['replans']} replans, {st_b['on_demand']} on demand")
+    assert st_b["plans"] >= 4
+    assert same_pdus(a, b) and len(b) >= n_packets // 3
+    assert tr_a.tobytes() == tr_b.tobytes()
+    assert st_b["launches"] <= 8 * st_b["plans"] + 3 * (st_b["replans"] + st_b["on_demand"])
+    c, tr_c, st_c = run_block(g, sf, f, 0, [cap], plan=1, feed=lambda p: torch.from_numpy(np.ascontiguousarray(p)).cuda())
+    assert same_pdus(a, c) and tr_a.tobytes() == tr_c.tobytes() and st_c["plans"] >= 4
+    cut = (len(cap) * 5 // 9) | 1
+    d, tr_d, st_d = run_block(g, sf, f, 0, [cap[:cut], cap[cut:]], plan=1)
+    assert same_pdus(a, d) and tr_a.tobytes() == tr_d.tobytes() and st_d["plans"] >= 4
+
+
 def test_plan_uses_preloaded_lattice(g):
     """Results handed in through lora_demod_core_preload for all 16 phases replace the plan's own lattice sweep."""
     sf, f = 8, 2; n = 1 << sf; step = n // 16
