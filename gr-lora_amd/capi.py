@@ -29,6 +29,7 @@ EXPORTS = (
     "lora_hip_strerror", "lora_hip_last_hip_error", "lora_hip_make_chirp_tables", "lora_hip_make_kaiser",
     "lora_hip_demod_create", "lora_hip_demod_destroy", "lora_hip_demod_set_stream", "lora_hip_demod_batch",
     "lora_hip_demod_batch_strided", "lora_hip_demod_batch_strided_noalloc", "lora_hip_demod_batch_runs", "lora_hip_demod_sync",
+    "lora_hip_demod_mark", "lora_hip_demod_wait",
     "lora_hip_host_alloc", "lora_hip_host_free", "lora_hip_demod_sf", "lora_hip_demod_fft_factor",
     "lora_hip_demod_kernel_name", "lora_hip_demod_stage_iq", "lora_hip_demod_stage_iq2",
     "lora_hip_demod_stage_iq2_dev", "lora_hip_demod_fetch", "lora_demod_core_work_device", "lora_demod_core_set_stream",
@@ -109,6 +110,8 @@ def lib():
     L.lora_demod_core_collected.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.lora_demod_core_collected.restype = i
     L.lora_hip_demod_batch_runs.argtypes = [vp, vp, sz, vp, sz, vp, vp, u]; L.lora_hip_demod_batch_runs.restype = i
     L.lora_hip_demod_sync.argtypes = [vp, i]; L.lora_hip_demod_sync.restype = i
+    L.lora_hip_demod_mark.argtypes = [vp, i, i]; L.lora_hip_demod_mark.restype = i
+    L.lora_hip_demod_wait.argtypes = [vp, i]; L.lora_hip_demod_wait.restype = i
     L.lora_hip_host_alloc.argtypes = [C.POINTER(vp), sz]; L.lora_hip_host_alloc.restype = i
     L.lora_hip_host_free.argtypes = [vp]; L.lora_hip_host_free.restype = None
     for nme in ("lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches",

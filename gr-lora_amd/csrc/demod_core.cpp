@@ -14,6 +14,7 @@
 #include "lora_demod_core.h"
 
 #include <chrono>
+#include <immintrin.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,6 +140,14 @@ struct Hist {
   const unsigned short *data() const { return buf + head; }
 };
 
+// x / fft_size_factor without a division when the factor is a power of two (it almost always is; N always is, so `% N`
+// is a mask): the state machine makes three such divisions per header/payload call and two per SFD window
+struct DivF {
+  unsigned f = 1, sh = 0; bool p2 = true;
+  void set(unsigned factor) { f = factor; p2 = factor && !(factor & (factor - 1)); sh = p2 ? (unsigned)__builtin_ctz(factor) : 0; }
+  unsigned operator()(unsigned x) const { return p2 ? x >> sh : x / f; }
+};
+
 // everything general_work reads and writes between calls (demod_impl.h:43-70) plus the read index: a dry run saves and
 // restores exactly this
 struct WalkState {
@@ -149,15 +158,20 @@ struct WalkState {
   unsigned d_preamble_idx = 0, d_sfd_idx = 0;
   Hist<REQUIRED_PREAMBLE_CHIRPS> d_argmax_history; Hist<REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR> d_sfd_history;
   unsigned d_sync_recovery_counter = 0;
+  unsigned sfd_agree = 0;       // bookkeeping of the SFD test (general_work), cleared with d_sfd_history
   std::vector<unsigned short> d_symbols;
   uint64_t pos = 0;
   uint64_t n_pdus = 0;          // PDUs emitted on this stream so far
 };
 
+constexpr unsigned kPlans = 4;
+static_assert(2 * kPlans <= LORA_HIP_MARKS, "one mark per plan for its lattice sweep, one for its SFD stage");
+
 struct lora_demod_core : WalkState {
   // configuration (demod_impl.h:44-49)
   unsigned d_sf = 0; bool d_ldr = false; float d_beta = 0; unsigned d_fft_size_factor = 0;
   unsigned d_num_symbols = 0, d_fft_size = 0;
+  DivF div_f;
   lora_hip_demod_t *hip = nullptr;
   // stream framing: the samples [base, base + total()) of the framed stream are buf (carried over from
   // earlier calls) followed, during a work() call, by that call's input, which is never copied on the
@@ -173,7 +187,7 @@ struct lora_demod_core : WalkState {
   // planned evaluation (Plan above): mode 0 off, 1 when the input is long enough to pay for it, 2 always
   // Three plans: a long input is planned in stretches, and while the state machine walks one stretch (`planp`) the GPU
   // already evaluates the SFD stage of the next and the lattice sweep of the one after (pipeline_run)
-  Plan plans[3]; Plan *planp = &plans[0]; int plan_mode = 1;
+  Plan plans[kPlans]; Plan *planp = &plans[0]; int plan_mode = 1;
   Plan &cur() { return *planp; }
   unsigned walk_lane = 0;        // LORA_HIP_LANE1 while stretches are in flight: what the walk launches must not queue behind them
   // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs about 0.07 ms of launches,
@@ -182,7 +196,7 @@ struct lora_demod_core : WalkState {
   size_t stretch_min = 180000;
   bool shadow = false;           // dry run: no launches, no PDUs, misses are predicted and recorded in `needs`
   std::vector<PRun> needs;
-  std::vector<uint16_t> fire;
+  std::vector<uint32_t> fire;      // plan_sfd: the lattice positions at which the preamble rule holds
   // first pass of a plan (plan_walk): the dry run keeps its trace rows and PDUs, to be completed from the READ stage
   bool deferred = false, pred = false;
   std::vector<Patch> patches; std::vector<Snap> snaps;
@@ -192,10 +206,11 @@ struct lora_demod_core : WalkState {
   bool collect = false;                                        // lora_demod_core_set_collect
   std::vector<uint16_t> col_syms; std::vector<uint64_t> col_off;
   long fault_at = -1; uint64_t n_pred = 0, n_rollbacks = 0;    // LORA_CORE_FAULT: test hook, mispredict that window
+  bool no_fast = false;          // LORA_CORE_NO_FAST=1: every call of the first pass through general_work (tests compare the two)
   uint64_t n_plans = 0, n_replans = 0, n_demand = 0;
   // LORA_CORE_TIMING=1: seconds per stage of the last work() call on stderr (lattice sweep, SFD scan, SFD launch, dry
   // run, READ launch, state machine)
-  bool timing = false; double t_stage[6] = {0, 0, 0, 0, 0, 0}, t_cb = 0;
+  bool timing = false; double t_stage[6] = {0, 0, 0, 0, 0, 0}, t_cb = 0, t_wait = 0, t_real = 0;
   // GPU result caches
   std::vector<Run> up_runs;      // launched by this core, bounded (kMaxRuns)
   size_t last_up = 0;            // index of the sweep that answered the last up-path lookup
@@ -392,6 +407,50 @@ inline bool planned_find(const std::vector<PRun> &L, size_t &cur, uint64_t pos, 
 
 int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consumed);
 
+// The preamble rule's index part (:247-262) at every lattice position j >= 48 of a sweep: the bins at j-16, j-32, j-48 (the
+// three older windows of j's phase) within LORA_PREAMBLE_TOLERANCE of the bin at j.  Writes the positions at which it holds,
+// in order, and returns their number.  |a - b| <= 1  <=>  (u16)(a - b + 1) <= 2 for bins below 65535.
+static_assert(LORA_PREAMBLE_TOLERANCE == 1, "the wrap-around compare below is written for a tolerance of 1");
+static_assert(OVERLAP_FACTOR == 16 && REQUIRED_PREAMBLE_CHIRPS == 4, "rule_hits looks 16, 32 and 48 positions back");
+inline bool rule_at(const uint16_t *ai, size_t j) {
+  const unsigned short i0 = ai[j];
+  return ((unsigned short)(i0 - ai[j - 16] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 32] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 48] + 1) <= 2);
+}
+size_t rule_hits_sse2(const uint16_t *ai, size_t count, uint32_t *hits) {
+  size_t nh = 0, j = 48;
+  const __m128i one = _mm_set1_epi16(1), two = _mm_set1_epi16(2), zero = _mm_setzero_si128();
+  for (; j + 8 <= count; j += 8) {
+    const __m128i i1 = _mm_add_epi16(_mm_loadu_si128((const __m128i *)(ai + j)), one);
+    const __m128i d1 = _mm_subs_epu16(_mm_sub_epi16(i1, _mm_loadu_si128((const __m128i *)(ai + j - 16))), two);
+    const __m128i d2 = _mm_subs_epu16(_mm_sub_epi16(i1, _mm_loadu_si128((const __m128i *)(ai + j - 32))), two);
+    const __m128i d3 = _mm_subs_epu16(_mm_sub_epi16(i1, _mm_loadu_si128((const __m128i *)(ai + j - 48))), two);
+    unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_or_si128(_mm_or_si128(d1, d2), d3), zero));
+    while (m) { const unsigned b = (unsigned)__builtin_ctz(m); hits[nh++] = (uint32_t)(j + b / 2); m &= ~(3u << b); }
+  }
+  for (; j < count; j++) if (rule_at(ai, j)) hits[nh++] = (uint32_t)j;
+  return nh;
+}
+__attribute__((target("avx2"))) size_t rule_hits_avx2(const uint16_t *ai, size_t count, uint32_t *hits) {
+  size_t nh = 0, j = 48;
+  const __m256i one = _mm256_set1_epi16(1), two = _mm256_set1_epi16(2), zero = _mm256_setzero_si256();
+  __m256i b1, b2, b3;
+  if (count >= 64) {
+    b3 = _mm256_loadu_si256((const __m256i *)(ai)); b2 = _mm256_loadu_si256((const __m256i *)(ai + 16)); b1 = _mm256_loadu_si256((const __m256i *)(ai + 32));
+    for (; j + 16 <= count; j += 16) {                  // the three older vectors are the last three loaded
+      const __m256i i0 = _mm256_loadu_si256((const __m256i *)(ai + j));
+      const __m256i i1 = _mm256_add_epi16(i0, one);
+      const __m256i d1 = _mm256_subs_epu16(_mm256_sub_epi16(i1, b1), two);
+      const __m256i d2 = _mm256_subs_epu16(_mm256_sub_epi16(i1, b2), two);
+      const __m256i d3 = _mm256_subs_epu16(_mm256_sub_epi16(i1, b3), two);
+      unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi16(_mm256_or_si256(_mm256_or_si256(d1, d2), d3), zero));
+      while (m) { const unsigned b = (unsigned)__builtin_ctz(m); hits[nh++] = (uint32_t)(j + b / 2); m &= ~(3u << b); }
+      b3 = b2; b2 = b1; b1 = i0;
+    }
+  }
+  for (; j < count; j++) if (rule_at(ai, j)) hits[nh++] = (uint32_t)j;
+  return nh;
+}
+
 // SFD stage: behind every lattice position of A at which the preamble rule holds (:247-273: the newest four windows of
 // one phase within +-1 of the newest, not squelched), the windows one sync attempt entered there can evaluate
 int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
@@ -404,24 +463,16 @@ int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
   const float thr = c->d_threshold;
   size_t total = 0;
   const size_t lag = OVERLAP_FACTOR;
-  // the rule for every lattice position at once (straight-line code the compiler vectorises), then the few hits
-  static_assert(LORA_PREAMBLE_TOLERANCE == 1, "the wrap-around compare below is written for a tolerance of 1");
-  c->fire.resize(P.a_count + 8);
-  uint16_t *fire = c->fire.data();
-  memset(fire, 0, (P.a_count < 3 * lag ? P.a_count : 3 * lag) * sizeof(uint16_t));
-  memset(fire + P.a_count, 0, 8 * sizeof(uint16_t));
-  for (size_t j = 3 * lag; j < P.a_count; j++) {        // 16-bit lanes only: eight positions per SSE2 operation
-    const unsigned short i0 = ai[j];
-    // |a - b| <= 1  <=>  (u16)(a - b + 1) <= 2 for bins below 65535
-    fire[j] = (uint16_t)(((unsigned short)(i0 - ai[j - lag] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 2 * lag] + 1) <= 2) &
-                         ((unsigned short)(i0 - ai[j - 3 * lag] + 1) <= 2));
-  }
-  for (size_t j = 3 * lag; j < P.a_count && total < kPlanMaxSfd; j++) {
-    if (!fire[j]) {
-      uint64_t w;
-      while (j + 4 < P.a_count && (memcpy(&w, fire + j, 8), w == 0)) j += 4;
-      if (!fire[j]) continue;
-    }
+  // the rule for every lattice position at once (16-bit lanes, 8 or 16 positions per operation), then the few hits
+  c->fire.resize(P.a_count + 1);
+  uint32_t *fire = c->fire.data();
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  const size_t n_fire = have_avx2 ? rule_hits_avx2(ai, P.a_count, fire) : rule_hits_sse2(ai, P.a_count, fire);
+  const double t_rule = now_s();
+  uint64_t back_lo[OVERLAP_FACTOR] = {0};                  // per phase: lattice index at which its last sweep starts
+  for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd[ph].clear();
+  for (size_t f = 0; f < n_fire && total < kPlanMaxSfd; f++) {
+    const size_t j = fire[f];
     if (!(av[j] > thr)) continue;                       // squelched (:268): no sync attempt
     const uint64_t lo = j + lag;                           // the sync attempt's first call is the next one on this phase
     uint64_t hi = lo + kSfdSpan;
@@ -431,7 +482,7 @@ int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
     std::vector<PRun> &L = P.sfd[ph];
     if (!L.empty()) {
       PRun &b = L.back();
-      const uint64_t blo = (b.start - P.a_start) / step;
+      const uint64_t blo = back_lo[ph];
       if (lo <= blo + b.count) {                           // overlaps or touches the last sweep of this phase
         // An attempt entered later in the same preamble locks at the same place or not at all: the sweep grows by one
         // call beyond what its first attempt can use, not by a full attempt per position (the rest, if ever asked
@@ -447,9 +498,10 @@ int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
     PRun r;
     r.start = P.a_start + lo * step; r.stride = step; r.count = (uint32_t)(hi - lo);
     r.off0 = (unsigned)(((r.start % n) + n - ph * step) % n); r.off_step = step;
-    L.push_back(r);
+    L.push_back(r); back_lo[ph] = lo;
     total += r.count;
   }
+  const double t_hits = now_s();
   std::vector<PRun *> all;
   for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) {
     if (split_input(c)) {                                  // cut the sweeps that straddle the end of the carry
@@ -463,6 +515,8 @@ int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
   const double t1 = now_s();
   const int rc = launch_planned(c, all, LORA_WIN_SFD, P.s_idx, nullptr, xflags);
   c->t_stage[1] += t1 - t0; c->t_stage[2] += now_s() - t1;
+  if (c->timing) fprintf(stderr, "[core]   SFD stage: %zu lattice positions, rule holds at %zu, %zu sweeps, %zu windows; scan %.3f ms (rule %.3f, hits %.3f, lists %.3f)\n", P.a_count, n_fire,
+                         all.size(), total, (t1 - t0) * 1e3, (t_rule - t0) * 1e3, (t_hits - t_rule) * 1e3, (t1 - t_hits) * 1e3);
   return rc;
 }
 
@@ -523,6 +577,62 @@ void trim_idle(lora_demod_core *c) {
   if (last < r.last) r.last = last;
 }
 
+// The header/payload calls of one packet in the first pass, behind the packet's first (which general_work has made and
+// which opened the READ sweep in `needs`): what general_work does for such a call -- get_up's prediction from the lattice
+// results, :133-137, :207-212, :363-413 -- with everything that cannot change between two of them looked up once.  The
+// calls go on for as long as the state machine stays in READ_HEADER/READ_PAYLOAD, lie one symbol apart (num_consumed = N)
+// and are answered from A at every 16th lattice position.  Returns false without having done anything when a condition
+// of the short cut does not hold; the caller then makes the call through general_work.
+bool first_pass_reads(lora_demod_core *c, Plan &P, uint64_t need, uint64_t a_last) {
+  const unsigned N = c->d_num_symbols, step = N / OVERLAP_FACTOR;
+  const unsigned off = c->d_offset;
+  // get_up would look in these first (exact results), and the test hook counts predictions
+  if (off == 0 || !c->up_runs.empty() || !c->pre_runs.empty() || c->fault_at >= 0 || !P.rd.empty() || c->needs.empty()) return false;
+  PRun &nr = c->needs.back();
+  if (nr.off0 != off || nr.start + (uint64_t)nr.count * N != c->pos) return false;
+  size_t k;
+  if (!plan_a_find(P, c->pos, step, &k)) return false;
+  const uint16_t *ai = P.a_idx.p; const float *av = P.a_val.p;
+  const float thr = c->d_threshold;
+  const uint64_t end = c->base + c->total();
+  const DivF div_f = c->div_f;
+  const unsigned pre = div_f(c->d_preamble_idx);
+  const bool ldr = c->d_ldr;
+  uint64_t pos = c->pos, calls = c->n_calls;
+  int state = c->d_state;
+  bool any = false;
+  while ((state == LORA_S_READ_HEADER || state == LORA_S_READ_PAYLOAD) && k < P.a_count && end >= pos + need && pos <= a_last) {
+    const unsigned short idx = ai[k]; const float val = av[k];
+    const bool sq = !(val > thr);                                      // :133-137
+    c->d_argmax_history.push_front(idx);                               // :207-212
+    if (c->d_argmax_history.size() > REQUIRED_PREAMBLE_CHIRPS) c->d_argmax_history.pop_back();
+    const int st_in = state;
+    const unsigned sym = (N + div_f(idx) - pre) & (N - 1);
+    uint8_t div4;
+    if (state == LORA_S_READ_HEADER) {                                 // :363-387
+      if (sq) state = LORA_S_OUT;
+      else if (c->d_symbols.size() == 7) state = LORA_S_READ_PAYLOAD;
+      div4 = 1;
+    } else {                                                           // :391-413
+      if (sq) state = LORA_S_OUT;
+      div4 = ldr ? 1 : 0;
+    }
+    c->d_symbols.push_back((unsigned short)(div4 ? sym / 4 : sym));
+    c->patches.push_back(Patch{pos, (uint32_t)calls, (uint32_t)(c->pdu_syms.size() + c->d_symbols.size() - 1),
+                               (uint16_t)off, (uint16_t)c->d_preamble_idx, div4, (uint8_t)sq});
+    if (c->trace && calls < c->max_trace) {
+      lora_core_trace &t = c->trace[calls];
+      t.pos = pos; t.state = (uint16_t)st_in; t.chirp_off = (uint16_t)off; t.idx = idx;
+      t.consumed = (uint16_t)N; t.val = val; t.n_sfd = 0;
+    }
+    c->d_power = val; c->d_squelched = sq;
+    nr.count++; calls++; pos += N; k += OVERLAP_FACTOR;
+    any = true;
+  }
+  c->d_state = state; c->pos = pos; c->n_calls = calls;
+  return any;
+}
+
 // First pass of a plan: the state machine runs ONCE over what is known, as in plan_reads, but keeps what it produces --
 // trace rows, PDUs -- with the header/payload calls answered from predictions (the squelch from A, the bin unknown).
 // After the READ stage has evaluated those windows, every predicted squelch decision is checked against the exact
@@ -530,9 +640,10 @@ void trim_idle(lora_demod_core *c) {
 // (:363-413 arithmetic) and trace rows.  The state machine is then put back at the last call that entered S_RESET
 // (which clears all state, :215-229) and runs for real from there, so that its final state never rests on a prediction.
 // A decision that does not hold puts it back at the S_RESET call before that packet instead.
-int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
+template <typename Between>
+int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user, bool overlap, Between between) {
   Plan &P = c->cur();
-  const unsigned n = c->d_num_symbols, F = c->d_fft_size_factor;
+  const unsigned n = c->d_num_symbols;
   P.rd.clear(); P.rd_cur = 0; c->needs.clear();
   c->patches.clear(); c->snaps.clear(); c->pdu_syms.clear(); c->pdu_off.clear();
   const double t0 = now_s();
@@ -543,12 +654,30 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   const uint64_t a_last = P.walk_end;
   int rc = LORA_HIP_OK;
   try {
+#ifdef LORA_CORE_PROFILE
+    uint64_t cyc[9] = {0}, cnt[9] = {0};
+#endif
     while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
+#ifdef LORA_CORE_PROFILE
+      const int st = c->d_state; const uint64_t tc0 = __rdtsc(), nc0 = c->n_calls;
+      if ((c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) && !c->no_fast && first_pass_reads(c, P, need, a_last)) {
+        cyc[8] += __rdtsc() - tc0; cnt[8] += c->n_calls - nc0; continue;
+      }
+#else
+      if ((c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) && !c->no_fast && first_pass_reads(c, P, need, a_last)) continue;
+#endif
       unsigned consumed = 0;
       rc = general_work(c, nullptr, nullptr, &consumed);
+#ifdef LORA_CORE_PROFILE
+      cyc[st & 7] += __rdtsc() - tc0; cnt[st & 7]++;
+#endif
       if (rc) break;
       c->pos += consumed;
     }
+#ifdef LORA_CORE_PROFILE
+    for (int i = 0; i < 9; i++) if (cnt[i]) fprintf(stderr, "[core]     state %d%s: %llu calls, %llu cycles, %.1f per call\n", i, i == 8 ? " (short cut)" : "",
+                                                    (unsigned long long)cnt[i], (unsigned long long)cyc[i], (double)cyc[i] / cnt[i]);
+#endif
   } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   c->shadow = false; c->deferred = false;
   const double t_walked = now_s();
@@ -567,9 +696,21 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   std::vector<PRun *> all;
   for (PRun &r : P.rd) all.push_back(&r);
   const double t1 = now_s();
-  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane);
+  // the READ stage's round trip (run list to HBM, launch, results back: ~60 us) passes while the host does `between`
+  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane | (overlap ? (unsigned)LORA_HIP_ASYNC : 0u));
+  const double t1b = now_s();
+  double t_between = 0, t_rsync = 0;
+  if (overlap) {
+    const int rb2 = rc ? LORA_HIP_OK : between();
+    const double t1c = now_s();
+    const int rs = lora_hip_demod_sync(c->hip, c->walk_lane ? 1 : 0);
+    t_between = t1c - t1b; t_rsync = now_s() - t1c;
+    c->t_stage[4] += t_rsync;
+    if (!rc && rb2) rc = rb2;
+    if (!rc && rs) rc = fail(c, rs, "sync");
+  }
   const double t2 = now_s();
-  c->t_stage[3] += t1 - t0; c->t_stage[4] += t2 - t1;
+  c->t_stage[3] += t1 - t0; c->t_stage[4] += t1b - t1;
   for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd_cur[ph] = 0;     // the read index goes back
   P.rd_cur = 0;
   if (rc) { to_start(); return rc; }
@@ -600,7 +741,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
         break;
       }
       const unsigned idx = P.r_idx.p[k];
-      const unsigned sym = (n + idx / F - pt.pre / F) % n;                   // :373, :398-401
+      const unsigned sym = (n + c->div_f(idx) - c->div_f(pt.pre)) & (n - 1);  // :373, :398-401
       c->pdu_syms[pt.flat] = (unsigned short)(pt.div4 ? sym / 4 : sym);
       if (c->trace && pt.row < c->max_trace) { c->trace[pt.row].idx = (uint16_t)idx; c->trace[pt.row].val = P.r_val.p[k]; }
     }
@@ -615,8 +756,9 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   trim_idle(c);
   P.rd_cur = 0;
   c->t_stage[3] += t3 - t2; c->t_cb += now_s() - t3;
-  if (c->timing) fprintf(stderr, "[core]   first pass: state machine %.3f ms (%llu calls) | run list %.3f | check + fill in %.3f (%zu predicted calls)\n",
-                         (t_walked - t0) * 1e3, (unsigned long long)(c->n_calls - saved_calls), (t1 - t_walked) * 1e3, (t3 - t2) * 1e3, c->patches.size());
+  if (c->timing) fprintf(stderr, "[core]   first pass: state machine %.3f ms (%llu calls) | run list %.3f | READ launch %.3f, meanwhile %.3f, then waited %.3f | check + fill in %.3f (%zu predicted calls)\n",
+                         (t_walked - t0) * 1e3, (unsigned long long)(c->n_calls - saved_calls), (t1 - t_walked) * 1e3, (t1b - t1) * 1e3, t_between * 1e3, t_rsync * 1e3,
+                         (t3 - t2) * 1e3, c->patches.size());
   return LORA_HIP_OK;
 }
 
@@ -659,12 +801,15 @@ int stage_lattice(lora_demod_core *c, Plan &P, uint64_t a_start, size_t count, u
 // Planned evaluation of one work() call (see struct Plan), in stretches that overlap in time.  The host's part of a plan --
 // the preamble rule over the lattice results, the first pass of the state machine, the check of its predictions -- is
 // strictly serial and as long as the GPU's part, so one plan for the whole input left each side idle half the time.  The
-// input is therefore cut into stretches of the lattice; per iteration k the host
-//     waits for lane 0 (lattice sweep of stretch k, SFD stage of stretch k-1),
-//     queues the lattice sweep of stretch k+1,
-//     evaluates the preamble rule of stretch k and queues its SFD stage,
-//     walks stretch k-1: first pass, READ stage (lane 1, so that it does not queue behind the sweeps), check, real run,
-// and the GPU works on stretches k and k+1 while the state machine is on k-1.  Stretches overlap by kStretchOverlap lattice
+// input is therefore cut into stretches of the lattice, each with a plan of its own (kPlans of them, used in turn).  Lane 0
+// is filled ahead of the state machine -- sweep 0, sweep 1, SFD 0, sweep 2, SFD 1, ... -- with a mark behind every item
+// (lora_hip_demod_mark), so that the host waits for the one result it needs next and not for the lane.  The host
+//     evaluates the preamble rule of stretches 0 and 1 as their sweeps arrive and queues their SFD stages, then per stretch k
+//     waits for the SFD stage of k,
+//     walks k: first pass, READ stage queued (lane 1, so that it does not wait behind the sweeps),
+//     evaluates the rule of stretch k+2 and queues its SFD stage while the READ stage is on its way,
+//     waits for lane 1, checks the first pass against the READ results and runs the state machine for real.
+// Stretches overlap by kStretchOverlap lattice
 // positions and the state machine changes plans in the middle of the overlap: far enough into the next stretch for the
 // preamble rule's three windows of history and for a sync attempt still in progress (at most 10 calls, :283-292) to have
 // been entered inside it.  What a plan holds for a window is exact whichever stretch evaluated it, and whatever no plan
@@ -693,40 +838,66 @@ int pipeline_run(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   auto a_start = [&](size_t k) { return p0 + (uint64_t)(k ? k * S - kStretchOverlap : 0) * step; };
   auto a_last = [&](size_t k) { const uint64_t e = p0 + (uint64_t)((k + 1) * S - 1) * step; return (k + 1 == K || e > last) ? last : e; };
   auto walk_end = [&](size_t k) { return k + 1 == K ? a_last(k) : a_last(k) - (uint64_t)(kStretchOverlap / 2) * step; };
-  auto issue_lattice = [&](size_t k) {
-    return stage_lattice(c, c->plans[k % 3], a_start(k), (size_t)((a_last(k) - a_start(k)) / step + 1), walk_end(k),
-                         K > 1 ? (unsigned)LORA_HIP_ASYNC : 0u);
+  if (K == 1) {                                          // one stretch: the three stages in order, on the one lane
+    Plan &P = c->plans[0];
+    int rc = stage_lattice(c, P, a_start(0), (size_t)((a_last(0) - a_start(0)) / step + 1), walk_end(0), 0);
+    if (!rc) rc = plan_sfd(c, P, 0);
+    if (rc) return rc;
+    c->planp = &P; P.active = true;
+    return plan_walk(c, cb, user, false, [] { return (int)LORA_HIP_OK; });   // the caller's loop runs it to the end of the input
+  }
+  const unsigned async = LORA_HIP_ASYNC;
+  c->walk_lane = LORA_HIP_LANE1;
+  size_t next_lat = 0, next_scan = 0, walked = 0;
+  int rc = LORA_HIP_OK;
+  auto marked = [&](int r, const char *what) { return r ? fail(c, r, what) : (int)LORA_HIP_OK; };
+  auto issue_lat = [&]() {
+    const size_t k = next_lat++;
+    int r = stage_lattice(c, c->plans[k % kPlans], a_start(k), (size_t)((a_last(k) - a_start(k)) / step + 1), walk_end(k), async);
+    if (!r) r = marked(lora_hip_demod_mark(c->hip, 0, (int)(k % kPlans)), "mark");
+    return r;
   };
-  const unsigned async = K > 1 ? (unsigned)LORA_HIP_ASYNC : 0u;
-  c->walk_lane = K > 1 ? (unsigned)LORA_HIP_LANE1 : 0u;
-  int rc = issue_lattice(0);
-  for (size_t k = 0; !rc && k <= K; k++) {
-    if (async && (rc = lora_hip_demod_sync(c->hip, 0))) { rc = fail(c, rc, "sync"); break; }
-    if (k + 1 < K && (rc = issue_lattice(k + 1))) break;
-    if (k < K) {
-      Plan &Q = c->plans[k % 3];
-      Q.active = true;                                   // plan_sfd reads its lattice results
-      rc = plan_sfd(c, Q, async);
-      Q.active = false;
-      if (rc) break;
-    }
-    if (k >= 1) {
-      c->planp = &c->plans[(k - 1) % 3];
-      Plan &P = c->cur();
+  // the preamble rule over the next stretch and its SFD stage, queued; behind it the lattice sweep two stretches further on,
+  // so that lane 0 holds sweep, sweep, SFD, sweep, SFD, ... and neither the GPU nor the first walk waits for long
+  auto scan = [&]() {
+    const size_t k = next_scan++;
+    const double tw = now_s();
+    int r = marked(lora_hip_demod_wait(c->hip, (int)(k % kPlans)), "wait");
+    c->t_wait += now_s() - tw;
+    if (!r) r = plan_sfd(c, c->plans[k % kPlans], async);
+    if (!r) r = marked(lora_hip_demod_mark(c->hip, 0, (int)(kPlans + k % kPlans)), "mark");
+    if (!r && next_lat < K && next_lat < walked + kPlans) r = issue_lat();
+    return r;
+  };
+  if (!(rc = issue_lat()) && !(rc = issue_lat()) && !(rc = scan())) rc = scan();
+  for (size_t k = 0; !rc && k < K; k++) {
+    const double tw = now_s();
+    if ((rc = marked(lora_hip_demod_wait(c->hip, (int)(kPlans + k % kPlans)), "wait"))) break;
+    c->t_wait += now_s() - tw;
+    c->planp = &c->plans[k % kPlans];
+    Plan &P = c->cur();
+    if (c->pos <= P.walk_end) {                          // (else the state machine is already past this stretch: a long SFD skip)
       P.active = true;
-      if (c->pos > P.walk_end) { P.active = false; continue; }      // the state machine is already past this stretch (a long SFD skip)
-      if ((rc = plan_walk(c, cb, user))) break;
-      if (k == K) break;                                 // the last stretch: the caller's loop runs it to the end of the input
+      // the rule over stretch k+2 is evaluated while the READ stage of stretch k is on its way
+      if ((rc = plan_walk(c, cb, user, true, [&] { return next_scan < K && next_scan <= k + 2 ? scan() : (int)LORA_HIP_OK; }))) break;
+      if (k + 1 == K) break;                             // the last stretch: the caller's loop runs it to the end of the input
+      const double tr = now_s();
       while (c->base + c->total() >= c->pos + need && c->pos <= P.walk_end) {
         unsigned consumed = 0;
         if ((rc = general_work(c, cb, user, &consumed))) break;
         c->pos += consumed;
       }
+      c->t_real += now_s() - tr;
       P.active = false;
+      if (rc) break;
     }
+    walked = k + 1;                                      // this stretch's plan is free for the stretch kPlans further on
+    while (!rc && next_scan < K && next_scan <= k + 2) rc = scan();
+    while (!rc && next_lat < K && next_lat < walked + kPlans) rc = issue_lat();
   }
   if (rc) {
     (void)lora_hip_demod_sync(c->hip, 0);              // nothing may still write a plan's arrays when the caller sees the error
+    (void)lora_hip_demod_sync(c->hip, 1);
     for (Plan &P : c->plans) P.active = false;
   }
   c->walk_lane = 0;
@@ -896,7 +1067,7 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       c->d_offset = 0;
       c->d_symbols.clear();
       c->d_argmax_history.clear();
-      c->d_sfd_history.clear();
+      c->d_sfd_history.clear(); c->sfd_agree = 0;
       c->d_sync_recovery_counter = 0;
       c->d_state = LORA_S_PREFILL;
       break;
@@ -913,37 +1084,40 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
       if (preamble_found && !c->d_squelched) c->d_state = LORA_S_SFD_SYNC;
       break;
 
-    case LORA_S_SFD_SYNC:                                           // :279-359
+    case LORA_S_SFD_SYNC: {                                         // :279-359
       c->d_overlaps = OVERLAP_FACTOR;
       if (c->d_sync_recovery_counter++ > DEMOD_SYNC_RECOVERY_COUNT) {
         c->d_state = LORA_S_RESET;
         c->d_overlaps = OVERLAP_DEFAULT;
       }
+      const unsigned ovl_sh = (unsigned)__builtin_ctz(c->d_overlaps);
+      const int tol = int(F) * LORA_SFD_TOLERANCE;
       for (int ol = 0; ol < (int)c->d_overlaps; ol++) {
-        c->d_offset = ((ol * N) / c->d_overlaps) % N;
+        c->d_offset = ((ol * N) >> ovl_sh) & (N - 1);                // ((ol * N) / d_overlaps) % N, d_overlaps 1 or 16
         if ((size_t)ol < seq_n) max_index = seq[ol];
         else if ((rc = get_sfd(c, c->pos, c->d_offset, &max_index, ol == 0 ? &seq : nullptr, &seq_n))) return rc;
         n_sfd++;
+        // sfd_agree: how many of the newest entries in a row lie within 2*tol of their predecessor.  The reference's test
+        // (every older entry within tol of the newest, :318-330) cannot hold unless all 31 pairs of the history do, so it
+        // is only evaluated then: one compare per window instead of a pass over the history whenever two windows agree
+        const bool adj = c->d_sfd_history.size() && abs(int(max_index) - int(c->d_sfd_history[0])) <= 2 * tol;
+        c->sfd_agree = adj ? c->sfd_agree + 1 : 0;
         c->d_sfd_history.push_front(max_index);
         if (c->d_sfd_history.size() > REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR) {
           c->d_sfd_history.pop_back();
-          c->d_sfd_idx = c->d_sfd_history[0];
-          // the reference's test (every older entry within the tolerance of the newest); the previous window alone
-          // settles it for almost every window, the rest is one pass without branches
-          const unsigned short *hs = c->d_sfd_history.data();
-          const int tol = int(F) * LORA_SFD_TOLERANCE;
-          sfd_found = !(abs(int(c->d_sfd_idx) - int(hs[1])) > tol);
-          if (sfd_found) {
+          c->d_sfd_idx = max_index;
+          if (c->sfd_agree >= REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR - 1) {
+            const unsigned short *hs = c->d_sfd_history.data();
             int worst = 0;
-            for (int i = 2; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++) {
-              const int dv = abs(int(c->d_sfd_idx) - int(hs[i]));
+            for (int i = 1; i < REQUIRED_SFD_CHIRPS * OVERLAP_FACTOR; i++) {
+              const int dv = abs(int(max_index) - int(hs[i]));
               worst = dv > worst ? dv : worst;
             }
             sfd_found = !(worst > tol);
           }
           if (sfd_found) {
-            num_consumed = (ol * N) / c->d_overlaps + 5 * N / 4;   // skip last quarter chirp
-            c->d_offset = (c->d_offset + (N / 4)) % N;
+            num_consumed = ((ol * N) >> ovl_sh) + 5 * N / 4;       // skip last quarter chirp
+            c->d_offset = (c->d_offset + (N / 4)) & (N - 1);
             c->d_state = LORA_S_READ_HEADER;
             c->d_overlaps = OVERLAP_DEFAULT;
             break;
@@ -951,11 +1125,12 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
         }
       }
       break;
+    }
 
     case LORA_S_READ_HEADER:                                        // :363-387
       if (c->d_squelched) c->d_state = LORA_S_OUT;
       else if (c->d_symbols.size() == 7) c->d_state = LORA_S_READ_PAYLOAD;
-      c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
+      c->d_symbols.push_back((unsigned short)(((N + c->div_f(c->d_argmax_history[0]) - c->div_f(c->d_preamble_idx)) & (N - 1)) / 4));
       if (c->deferred && pred)
         c->patches.push_back(Patch{c->pos, (uint32_t)c->n_calls, (uint32_t)(c->pdu_syms.size() + c->d_symbols.size() - 1),
                                    (uint16_t)off, (uint16_t)c->d_preamble_idx, 1, (uint8_t)c->d_squelched});
@@ -964,9 +1139,9 @@ int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consu
     case LORA_S_READ_PAYLOAD:                                       // :391-413
       if (c->d_squelched) c->d_state = LORA_S_OUT;
       if (c->d_ldr)
-        c->d_symbols.push_back((unsigned short)(((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N) / 4));
+        c->d_symbols.push_back((unsigned short)(((N + c->div_f(c->d_argmax_history[0]) - c->div_f(c->d_preamble_idx)) & (N - 1)) / 4));
       else
-        c->d_symbols.push_back((unsigned short)((N + (c->d_argmax_history[0] / F) - (c->d_preamble_idx / F)) % N));
+        c->d_symbols.push_back((unsigned short)((N + c->div_f(c->d_argmax_history[0]) - c->div_f(c->d_preamble_idx)) & (N - 1)));
       if (c->deferred && pred)
         c->patches.push_back(Patch{c->pos, (uint32_t)c->n_calls, (uint32_t)(c->pdu_syms.size() + c->d_symbols.size() - 1),
                                    (uint16_t)off, (uint16_t)c->d_preamble_idx, (uint8_t)(c->d_ldr ? 1 : 0), (uint8_t)c->d_squelched});
@@ -1009,9 +1184,10 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   if (rc) { delete c; return rc; }
   if (const char *e = getenv("LORA_CORE_FAULT")) c->fault_at = atol(e);
   if (const char *e = getenv("LORA_CORE_TIMING")) c->timing = atoi(e) != 0;
+  if (const char *e = getenv("LORA_CORE_NO_FAST")) c->no_fast = atoi(e) != 0;
   if (const char *e = getenv("LORA_CORE_STRETCH")) { const long v = atol(e); if (v >= 4096) c->stretch_min = (size_t)v; }
   if (const char *e = getenv("LORA_CORE_PLAN")) { const int m = atoi(e); if (m >= 0 && m <= 2) c->plan_mode = m; }
-  c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor;
+  c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor; c->div_f.set(fft_factor);
   c->d_num_symbols = 1u << sf;                                      // :79
   c->d_fft_size = c->d_fft_size_factor * c->d_num_symbols;          // :80
   // set_history(DEMOD_HISTORY_DEPTH * N), :103: the scheduler presents history()-1 zeros first
@@ -1027,7 +1203,7 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->d_overlaps = OVERLAP_DEFAULT; c->d_offset = 0;
   c->d_power = .000000001f; c->d_squelched = false;
   c->d_preamble_idx = 0; c->d_sfd_idx = 0;
-  c->d_argmax_history.clear(); c->d_sfd_history.clear(); c->d_symbols.clear();
+  c->d_argmax_history.clear(); c->d_sfd_history.clear(); c->d_symbols.clear(); c->sfd_agree = 0;
   c->d_sync_recovery_counter = 0;
   c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
   c->cur_in = nullptr; c->cur_n = 0;
@@ -1091,7 +1267,7 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   int rc = LORA_HIP_OK;
   c->col_syms.clear(); c->col_off.assign(1, 0);
   for (double &t : c->t_stage) t = 0;
-  c->t_cb = 0;
+  c->t_cb = 0; c->t_wait = 0; c->t_real = 0;
   const double t_begin = now_s();
   try { rc = pipeline_run(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   const double t_walk = now_s();
@@ -1103,6 +1279,8 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   }
   if (c->timing) {
     const double t_end = now_s();
+    fprintf(stderr, "[core]   waits for lane 0 %.3f ms | real runs inside the pipeline %.3f | real run behind it %.3f\n", c->t_wait * 1e3, c->t_real * 1e3,
+            (t_end - t_walk) * 1e3);
     c->t_stage[5] = t_end - t_walk - (c->t_stage[0] + c->t_stage[1] + c->t_stage[2] + c->t_stage[3] + c->t_stage[4] - (t_walk - t_begin));
     fprintf(stderr, "[core] work %zu samples: lattice sweep %.3f ms | SFD scan %.3f | SFD launch %.3f | dry run %.3f | READ launch %.3f | "
                     "state machine %.3f | PDU callbacks of the first pass %.3f | total %.3f ms; %llu launches so far\n", n_in, c->t_stage[0] * 1e3, c->t_stage[1] * 1e3,

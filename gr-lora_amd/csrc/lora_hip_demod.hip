@@ -54,8 +54,11 @@ struct lora_hip_demod {
   unsigned char *d_out1 = nullptr, *h_out1 = nullptr; size_t cap_out1 = 0;
   // run lists of lora_hip_demod_batch_runs: page-locked staging per lane, copied to HBM behind the call (no synchronisation);
   // the event says when the lane's last copy is done with it
-  unsigned char *h_runs[2] = {nullptr, nullptr}; size_t cap_hruns[2] = {0, 0};
-  hipEvent_t runs_done[2] = {nullptr, nullptr}; bool runs_pending[2] = {false, false};
+  // two blocks per lane, used in turn, so that a call waits for the copy of the call before the last, not for the last
+  unsigned char *h_runs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t cap_hruns[2][2] = {{0, 0}, {0, 0}};
+  hipEvent_t runs_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool runs_pending[2][2] = {{false, false}, {false, false}};
+  unsigned runs_turn[2] = {0, 0};
+  hipEvent_t marks[LORA_HIP_MARKS] = {nullptr};           // lora_hip_demod_mark / lora_hip_demod_wait
   int scratch_slot = -1;                 // this handle's slot of the per-device `scratch` (-1: all were taken at create)
   bool scratch_dirty = false;            // the same for the handle's scratch slot (each buffer has its own flag)
   long fault_at = -1, n_launch = 0;      // LORA_HIP_FAULT=n: test hook, the n-th launch on the handle fails and leaves its counters undefined
@@ -409,11 +412,21 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   if (hipMalloc((void **)&h->d_tw, tw.size() * sizeof(float2)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMalloc((void **)&h->d_ticket, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemset(h->d_ticket, 0, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_EHIP);
-  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(LORA_HIP_EHIP);
+  {
+    // the second lane is for small launches that must not wait behind the first lane's queue: highest priority, so that its
+    // workgroups go first when a running sweep lets go of the CUs
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+    if (getenv("LORA_HIP_NO_PRIORITY")) greatest = least;
+    if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, greatest) != hipSuccess) return fail(LORA_HIP_EHIP);
+  }
   if (hipMalloc((void **)&h->d_ticket1, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_ENOMEM);
   if (hipMemset(h->d_ticket1, 0, kScratchWords * sizeof(unsigned)) != hipSuccess) return fail(LORA_HIP_EHIP);
   for (int l = 0; l < 2; l++)
-    if (hipEventCreateWithFlags(&h->runs_done[l], hipEventDisableTiming) != hipSuccess) return fail(LORA_HIP_EHIP);
+    for (int b = 0; b < 2; b++)
+      if (hipEventCreateWithFlags(&h->runs_done[l][b], hipEventDisableTiming) != hipSuccess) return fail(LORA_HIP_EHIP);
+  for (int m = 0; m < LORA_HIP_MARKS; m++)
+    if (hipEventCreateWithFlags(&h->marks[m], hipEventDisableTiming) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_up, up.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_down, down.data(), 2 * n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
   if (hipMemcpy(h->d_win, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(LORA_HIP_EHIP);
@@ -467,10 +480,13 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
   DeviceGuard guard(h->device);
   if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
-  for (int l = 0; l < 2; l++) {
-    if (h->runs_done[l]) (void)hipEventDestroy(h->runs_done[l]);
-    if (h->h_runs[l]) (void)hipHostFree(h->h_runs[l]);
-  }
+  for (int l = 0; l < 2; l++)
+    for (int b = 0; b < 2; b++) {
+      if (h->runs_done[l][b]) (void)hipEventDestroy(h->runs_done[l][b]);
+      if (h->h_runs[l][b]) (void)hipHostFree(h->h_runs[l][b]);
+    }
+  for (int m = 0; m < LORA_HIP_MARKS; m++)
+    if (h->marks[m]) (void)hipEventDestroy(h->marks[m]);
   (void)hipFree(h->d_ticket1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_runs1); (void)hipFree(h->d_out1);
   if (h->h_out1) (void)hipHostFree(h->h_out1);
   if (h->scratch_slot >= 0 && h->device < kMaxDevices) {   // the slot goes back; the next owner clears it if this one left it undefined
@@ -669,15 +685,16 @@ int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_
   // The run list goes into page-locked memory of the handle and from there to HBM with an asynchronous copy (it used to be
   // copied from a pageable vector, which cost a stream synchronisation per call).  The lane's previous copy must be done
   // with that memory before it is overwritten.
-  if (h->runs_pending[lane]) { HIP_TRY(h, hipEventSynchronize(h->runs_done[lane])); h->runs_pending[lane] = false; }
-  if (n_runs * sizeof(RunDev) > h->cap_hruns[lane]) {
-    if (h->h_runs[lane]) { (void)hipHostFree(h->h_runs[lane]); h->h_runs[lane] = nullptr; h->cap_hruns[lane] = 0; }
+  const unsigned tb = h->runs_turn[lane]++ & 1u;
+  if (h->runs_pending[lane][tb]) { HIP_TRY(h, hipEventSynchronize(h->runs_done[lane][tb])); h->runs_pending[lane][tb] = false; }
+  if (n_runs * sizeof(RunDev) > h->cap_hruns[lane][tb]) {
+    if (h->h_runs[lane][tb]) { (void)hipHostFree(h->h_runs[lane][tb]); h->h_runs[lane][tb] = nullptr; h->cap_hruns[lane][tb] = 0; }
     const size_t ncap = (n_runs + n_runs / 4 + 64) * sizeof(RunDev);
-    hipError_t e = hipHostMalloc((void **)&h->h_runs[lane], ncap, hipHostMallocDefault);
-    if (e != hipSuccess) { h->h_runs[lane] = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
-    h->cap_hruns[lane] = ncap;
+    hipError_t e = hipHostMalloc((void **)&h->h_runs[lane][tb], ncap, hipHostMallocDefault);
+    if (e != hipSuccess) { h->h_runs[lane][tb] = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+    h->cap_hruns[lane][tb] = ncap;
   }
-  RunDev *rd = reinterpret_cast<RunDev *>(h->h_runs[lane]);
+  RunDev *rd = reinterpret_cast<RunDev *>(h->h_runs[lane][tb]);
   size_t n_rd = 0;
   uint64_t total = 0;
   for (size_t r = 0; r < n_runs; r++) {
@@ -699,8 +716,8 @@ int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_
   if ((rc = grow(h, &d_runs, &cap_runs, n_rd * sizeof(RunDev))) != LORA_HIP_OK) return rc;
   if ((rc = grow(h, reinterpret_cast<unsigned char **>(&d_desc), &cap_desc, (size_t)total * sizeof(lora_win_desc))) != LORA_HIP_OK) return rc;
   HIP_TRY(h, hipMemcpyAsync(d_runs, rd, n_rd * sizeof(RunDev), hipMemcpyHostToDevice, stream));
-  HIP_TRY(h, hipEventRecord(h->runs_done[lane], stream));
-  h->runs_pending[lane] = true;
+  HIP_TRY(h, hipEventRecord(h->runs_done[lane][tb], stream));
+  h->runs_pending[lane][tb] = true;
   hipLaunchKernelGGL(expand_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      reinterpret_cast<const RunDev *>(d_runs), (unsigned)n_rd, (unsigned)total, h->n - 1,
                      reinterpret_cast<lora_hip::WinDesc *>(d_desc));
@@ -717,6 +734,22 @@ int lora_hip_demod_sync(lora_hip_demod_t *h, int lane) {
   DeviceGuard guard(h->device);
   HIP_TRY(h, guard.err);
   HIP_TRY(h, hipStreamSynchronize(lane ? h->aux_stream : h->stream));
+  return LORA_HIP_OK;
+}
+
+int lora_hip_demod_mark(lora_hip_demod_t *h, int lane, int mark) {
+  if (!h || lane < 0 || lane > 1 || mark < 0 || mark >= LORA_HIP_MARKS) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  HIP_TRY(h, hipEventRecord(h->marks[mark], lane ? h->aux_stream : h->stream));
+  return LORA_HIP_OK;
+}
+
+int lora_hip_demod_wait(lora_hip_demod_t *h, int mark) {
+  if (!h || mark < 0 || mark >= LORA_HIP_MARKS) return LORA_HIP_EINVAL;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, guard.err);
+  HIP_TRY(h, hipEventSynchronize(h->marks[mark]));       // a mark never set counts as reached
   return LORA_HIP_OK;
 }
 

@@ -156,6 +156,14 @@ LORA_HIP_API int lora_hip_demod_batch_runs(lora_hip_demod_t *h, const lora_c32 *
  * reference (its general_work is synchronous, demod_impl.cc:149-450). */
 LORA_HIP_API int lora_hip_demod_sync(lora_hip_demod_t *h, int lane);
 
+/* Marks, for a caller that has several LORA_HIP_ASYNC calls queued on a lane and wants the results of one of them:
+ * lora_hip_demod_mark sets mark `mark` (0 <= mark < LORA_HIP_MARKS) behind everything queued on `lane` so far,
+ * lora_hip_demod_wait returns once the lane has reached it (at once for a mark that was never set).  Setting a mark
+ * again moves it.  No counterpart in the reference. */
+#define LORA_HIP_MARKS 8
+LORA_HIP_API int lora_hip_demod_mark(lora_hip_demod_t *h, int lane, int mark);
+LORA_HIP_API int lora_hip_demod_wait(lora_hip_demod_t *h, int mark);
+
 /* Page-locked host memory for LORA_HIP_OUT_PINNED result buffers (hipHostMalloc / hipHostFree). */
 LORA_HIP_API int lora_hip_host_alloc(void **p, size_t bytes);
 LORA_HIP_API void lora_hip_host_free(void *p);
