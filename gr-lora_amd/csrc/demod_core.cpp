@@ -190,9 +190,10 @@ struct lora_demod_core : WalkState {
   Plan plans[kPlans]; Plan *planp = &plans[0]; int plan_mode = 1;
   Plan &cur() { return *planp; }
   unsigned walk_lane = 0;        // LORA_HIP_LANE1 while stretches are in flight: what the walk launches must not queue behind them
-  // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs about 0.07 ms of launches,
-  // synchronisations and the READ stage's round trip; measured on 524 k positions (8.4 M samples at SF8, 386 packets,
-  // profiles/r03_pipeline.txt): 1 stretch 1.91 ms, 2 stretches 1.66, 4 stretches 1.70, 8 stretches 1.99
+  // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs its launches, a READ round
+  // trip that nothing hides (~0.06 ms, more when the READ launch has to wait for a running sweep to let go of the CUs) and the
+  // state machine's wait for its SFD stage; measured on 524 k positions (8.4 M samples at SF8, 386 packets,
+  // profiles/r03_pipeline.txt): 1 stretch 1.56 ms, 2 stretches 1.34, 3 stretches 1.36-1.42, 4 stretches 1.51, 7 stretches 1.57
   size_t stretch_min = 180000;
   bool shadow = false;           // dry run: no launches, no PDUs, misses are predicted and recorded in `needs`
   std::vector<PRun> needs;

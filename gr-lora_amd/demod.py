@@ -11,9 +11,59 @@ cons(make_dict(), u16vector) PDUs (lib/demod_impl.cc:58-60,74-75,420-422); here 
 """
 import ctypes as C
 
+from collections.abc import Sequence
+
 import numpy as np
 
 from . import capi
+
+
+class PduList(Sequence):
+    """The PDUs of one work() call, in order: u16 arrays cut out of one copy of the block's symbol buffer when they are
+    asked for (a few hundred numpy views cost more than the block's own host work on a dense capture).  Behaves as the
+    list it stands for: len, indexing, slicing, iteration, +, == against a list."""
+    __slots__ = ("_flat", "_off")
+
+    def __init__(self, flat, off):
+        self._flat, self._off = flat, off
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("PDU index out of range")
+        return self._flat[self._off[i]:self._off[i + 1]]
+
+    def __iter__(self):
+        flat, off = self._flat, self._off
+        for k in range(len(off) - 1):
+            yield flat[off[k]:off[k + 1]]
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(np.array_equal(a, b) for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"PduList({len(self)} PDUs)"
+
+
+_EMPTY = PduList(np.zeros(0, np.uint16), [0])
 
 
 class demod:
@@ -47,7 +97,7 @@ class demod:
         if rc:
             raise capi.LoraHipError(rc)
         self._handlers = []
-        self._pending = []
+        self._pending = _EMPTY
         self._trace = None
         self._cb = capi.PDU_CB(0)                # NULL: no per-PDU callback
 
@@ -79,16 +129,17 @@ class demod:
         rc = capi.lib().lora_demod_core_collected(self._h, C.byref(syms), C.byref(offs), C.byref(n))
         if rc:
             raise capi.LoraHipError(rc)
-        self._pending = []
+        self._pending = _EMPTY
         if n.value:
             o = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_uint64)), (n.value + 1,))
             total = int(o[-1])
             flat = np.ctypeslib.as_array(C.cast(syms, C.POINTER(C.c_uint16)), (total,)).copy() if total else np.zeros(0, np.uint16)
-            ol = o.tolist()
-            self._pending = [({}, flat[ol[k]:ol[k + 1]]) for k in range(n.value)]
-        for pdu in self._pending:
-            for h in self._handlers:
-                h(pdu)
+            self._pending = PduList(flat, o.tolist())
+        if self._handlers:
+            for vec in self._pending:
+                pdu = ({}, vec)
+                for h in self._handlers:
+                    h(pdu)
 
     def enable_trace(self, max_rows):
         self._trace = np.zeros(max_rows, capi.CORE_TRACE_DTYPE)
@@ -103,7 +154,7 @@ class demod:
         rc = capi.lib().lora_demod_core_reset(self._h)
         if rc:
             raise capi.LoraHipError(rc)
-        self._pending = []
+        self._pending = _EMPTY
 
     def seek(self, pos):
         """lora_demod_core_seek: a new stream that starts at framed-stream index pos in S_RESET; the next samples fed
@@ -111,7 +162,7 @@ class demod:
         rc = capi.lib().lora_demod_core_seek(self._h, int(pos))
         if rc:
             raise capi.LoraHipError(rc)
-        self._pending = []
+        self._pending = _EMPTY
 
     def idle_log(self):
         """lora_demod_core_idle_log as an (k, 3) uint64 array: first index, last index, PDUs emitted before."""
@@ -135,7 +186,7 @@ class demod:
     def work(self, samples):
         """Feed complex64 samples; returns the PDUs completed by this call as u16 arrays.  A torch cuda tensor
         (e.g. the channeliser's output) is read where it lies in HBM (lora_demod_core_work_device)."""
-        self._pending = []
+        self._pending = _EMPTY
         if capi._is_torch(samples) and samples.is_cuda:
             import torch
             assert samples.dtype == torch.complex64 and samples.is_contiguous()
@@ -151,7 +202,7 @@ class demod:
             self._fetch_pdus()            # PDUs completed before an error are still reported
             if rc:
                 raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
-            return [p[1] for p in self._pending]
+            return self._pending
         x = np.ascontiguousarray(samples, np.complex64)
         # host samples run on the block's own stream: a torch stream bound by an earlier device call may be gone by now
         rc = capi.lib().lora_demod_core_set_stream(self._h, None)
@@ -161,7 +212,7 @@ class demod:
         self._fetch_pdus()
         if rc:
             raise capi.LoraHipError(rc, capi.lib().lora_demod_core_last_error(self._h).decode())
-        return [p[1] for p in self._pending]
+        return self._pending
 
     @property
     def stats(self):
