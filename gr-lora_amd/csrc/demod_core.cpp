@@ -408,16 +408,19 @@ inline bool planned_find(const std::vector<PRun> &L, size_t &cur, uint64_t pos, 
 
 int general_work(lora_demod_core *c, lora_pdu_cb cb, void *user, unsigned *consumed);
 
-// The preamble rule's index part (:247-262) at every lattice position j >= 48 of a sweep: the bins at j-16, j-32, j-48 (the
-// three older windows of j's phase) within LORA_PREAMBLE_TOLERANCE of the bin at j.  Writes the positions at which it holds,
-// in order, and returns their number.  |a - b| <= 1  <=>  (u16)(a - b + 1) <= 2 for bins below 65535.
+// The preamble rule (:247-273) at every lattice position j >= 48 of a sweep: the bins at j-16, j-32, j-48 (the three older
+// windows of j's phase) within LORA_PREAMBLE_TOLERANCE of the bin at j, and the window at j not squelched (val > thr).  Writes
+// the positions at which it holds, in order, and returns their number.  |a - b| <= 1  <=>  (u16)(a - b + 1) <= 2 for bins
+// below 65535.  (A capture with exact zeros between its packets has the same bin everywhere: the squelch has to be part of
+// the vector test, or every position of an hour of silence is a candidate.)
 static_assert(LORA_PREAMBLE_TOLERANCE == 1, "the wrap-around compare below is written for a tolerance of 1");
 static_assert(OVERLAP_FACTOR == 16 && REQUIRED_PREAMBLE_CHIRPS == 4, "rule_hits looks 16, 32 and 48 positions back");
-inline bool rule_at(const uint16_t *ai, size_t j) {
+inline bool rule_at(const uint16_t *ai, const float *av, float thr, size_t j) {
   const unsigned short i0 = ai[j];
-  return ((unsigned short)(i0 - ai[j - 16] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 32] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 48] + 1) <= 2);
+  return (((unsigned short)(i0 - ai[j - 16] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 32] + 1) <= 2) & ((unsigned short)(i0 - ai[j - 48] + 1) <= 2)) &&
+         av[j] > thr;
 }
-size_t rule_hits_sse2(const uint16_t *ai, size_t count, uint32_t *hits) {
+size_t rule_hits_sse2(const uint16_t *ai, const float *av, float thr, size_t count, uint32_t *hits) {
   size_t nh = 0, j = 48;
   const __m128i one = _mm_set1_epi16(1), two = _mm_set1_epi16(2), zero = _mm_setzero_si128();
   for (; j + 8 <= count; j += 8) {
@@ -426,14 +429,19 @@ size_t rule_hits_sse2(const uint16_t *ai, size_t count, uint32_t *hits) {
     const __m128i d2 = _mm_subs_epu16(_mm_sub_epi16(i1, _mm_loadu_si128((const __m128i *)(ai + j - 32))), two);
     const __m128i d3 = _mm_subs_epu16(_mm_sub_epi16(i1, _mm_loadu_si128((const __m128i *)(ai + j - 48))), two);
     unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_or_si128(_mm_or_si128(d1, d2), d3), zero));
-    while (m) { const unsigned b = (unsigned)__builtin_ctz(m); hits[nh++] = (uint32_t)(j + b / 2); m &= ~(3u << b); }
+    while (m) {
+      const unsigned b = (unsigned)__builtin_ctz(m);
+      if (av[j + b / 2] > thr) hits[nh++] = (uint32_t)(j + b / 2);
+      m &= ~(3u << b);
+    }
   }
-  for (; j < count; j++) if (rule_at(ai, j)) hits[nh++] = (uint32_t)j;
+  for (; j < count; j++) if (rule_at(ai, av, thr, j)) hits[nh++] = (uint32_t)j;
   return nh;
 }
-__attribute__((target("avx2"))) size_t rule_hits_avx2(const uint16_t *ai, size_t count, uint32_t *hits) {
+__attribute__((target("avx2,bmi2"))) size_t rule_hits_avx2(const uint16_t *ai, const float *av, float thr, size_t count, uint32_t *hits) {
   size_t nh = 0, j = 48;
   const __m256i one = _mm256_set1_epi16(1), two = _mm256_set1_epi16(2), zero = _mm256_setzero_si256();
+  const __m256 vthr = _mm256_set1_ps(thr);
   __m256i b1, b2, b3;
   if (count >= 64) {
     b3 = _mm256_loadu_si256((const __m256i *)(ai)); b2 = _mm256_loadu_si256((const __m256i *)(ai + 16)); b1 = _mm256_loadu_si256((const __m256i *)(ai + 32));
@@ -444,11 +452,15 @@ __attribute__((target("avx2"))) size_t rule_hits_avx2(const uint16_t *ai, size_t
       const __m256i d2 = _mm256_subs_epu16(_mm256_sub_epi16(i1, b2), two);
       const __m256i d3 = _mm256_subs_epu16(_mm256_sub_epi16(i1, b3), two);
       unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi16(_mm256_or_si256(_mm256_or_si256(d1, d2), d3), zero));
-      while (m) { const unsigned b = (unsigned)__builtin_ctz(m); hits[nh++] = (uint32_t)(j + b / 2); m &= ~(3u << b); }
       b3 = b2; b2 = b1; b1 = i0;
+      if (!m) continue;
+      m = _pext_u32(m, 0x55555555u);                    // one bit per position
+      m &= (unsigned)_mm256_movemask_ps(_mm256_cmp_ps(_mm256_loadu_ps(av + j), vthr, _CMP_GT_OQ)) |
+           (unsigned)_mm256_movemask_ps(_mm256_cmp_ps(_mm256_loadu_ps(av + j + 8), vthr, _CMP_GT_OQ)) << 8;
+      while (m) { const unsigned b = (unsigned)__builtin_ctz(m); hits[nh++] = (uint32_t)(j + b); m &= m - 1; }
     }
   }
-  for (; j < count; j++) if (rule_at(ai, j)) hits[nh++] = (uint32_t)j;
+  for (; j < count; j++) if (rule_at(ai, av, thr, j)) hits[nh++] = (uint32_t)j;
   return nh;
 }
 
@@ -467,14 +479,13 @@ int plan_sfd(lora_demod_core *c, Plan &P, unsigned xflags = 0) {
   // the rule for every lattice position at once (16-bit lanes, 8 or 16 positions per operation), then the few hits
   c->fire.resize(P.a_count + 1);
   uint32_t *fire = c->fire.data();
-  static const bool have_avx2 = __builtin_cpu_supports("avx2");
-  const size_t n_fire = have_avx2 ? rule_hits_avx2(ai, P.a_count, fire) : rule_hits_sse2(ai, P.a_count, fire);
+  static const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+  const size_t n_fire = have_avx2 ? rule_hits_avx2(ai, av, thr, P.a_count, fire) : rule_hits_sse2(ai, av, thr, P.a_count, fire);
   const double t_rule = now_s();
   uint64_t back_lo[OVERLAP_FACTOR] = {0};                  // per phase: lattice index at which its last sweep starts
   for (unsigned ph = 0; ph < OVERLAP_FACTOR; ph++) P.sfd[ph].clear();
   for (size_t f = 0; f < n_fire && total < kPlanMaxSfd; f++) {
-    const size_t j = fire[f];
-    if (!(av[j] > thr)) continue;                       // squelched (:268): no sync attempt
+    const size_t j = fire[f];                           // (not squelched, :268: rule_hits has looked)
     const uint64_t lo = j + lag;                           // the sync attempt's first call is the next one on this phase
     uint64_t hi = lo + kSfdSpan;
     if (hi > jmax + 1) hi = jmax + 1;
