@@ -676,6 +676,12 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
   } else {
     Dft<16>::run(v);                                 // n2 -> ka
   }
+  constexpr bool kTwPre12 = LORA_TWPRE && twpre_fits(12, F) && !(LORA_ABL & 32);
+#ifndef LORA_P1_BASE
+#define LORA_P1_BASE 0     // 1: pass 1 reads only its base twiddle from LDS and forms the other seven factors (25 instructions)
+#endif
+  constexpr int NT1 = LORA_POLY16 ? 8 : 15;          // rows of the pass-1 table this kernel reads (the host fills them to match)
+  float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
 #if !(LORA_ABL & 32)
   LORA_STAMP(2);
   if (!(LORA_ABL & 128) && !LORA_EARLY_BARRIER) __syncthreads();   // every wave is done with the previous transform's rows
@@ -686,12 +692,6 @@ __device__ __forceinline__ void fft_sf12(float2 (&v)[16], float2 *tile, const fl
 #pragma unroll
     for (int m = 0; m < 16; m++) o[m * ROW] = v[m];  // tile[ka = m][n1 = hi][n0 = lo]
   }
-  constexpr bool kTwPre12 = LORA_TWPRE && twpre_fits(12, F) && !(LORA_ABL & 32);
-#ifndef LORA_P1_BASE
-#define LORA_P1_BASE 0     // 1: pass 1 reads only its base twiddle from LDS and forms the other seven factors (25 instructions)
-#endif
-  constexpr int NT1 = LORA_POLY16 ? 8 : 15;          // rows of the pass-1 table this kernel reads (the host fills them to match)
-  float2 t1[15];                                     // pass-1 twiddles (read-only table): in flight across the barrier
   if constexpr (kTwPre12) {
     const float2 *tp = lds_tw + pass_lds_offset(12, F, 1) + (rr * 15) * 16 + hi;
     if constexpr (LORA_P1_BASE && LORA_POLY16) t1[4] = lds_read<lds_single(12)>(&tp[4 * 16]);
