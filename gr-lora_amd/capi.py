@@ -38,6 +38,7 @@ EXPORTS = (
     "lora_demod_core_calls", "lora_demod_core_windows", "lora_demod_core_launches", "lora_demod_core_state",
     "lora_demod_core_last_error", "lora_demod_core_preload", "lora_demod_core_reset", "lora_demod_core_set_plan", "lora_demod_core_seek", "lora_demod_core_idle_log", "lora_demod_core_set_collect", "lora_demod_core_collected",
     "lora_demod_core_plans", "lora_demod_core_replans", "lora_demod_core_on_demand", "lora_demod_core_rollbacks",
+    "lora_demod_core_rule_hits",
     # include/lora_hip_chan.h
     "lora_hip_chan_design_taps", "lora_hip_chan_create", "lora_hip_chan_destroy", "lora_hip_chan_set_stream",
     "lora_hip_chan_last_hip_error", "lora_hip_chan_reset", "lora_hip_chan_output_count", "lora_hip_chan_work",
@@ -118,6 +119,7 @@ def lib():
                 "lora_demod_core_plans", "lora_demod_core_replans", "lora_demod_core_on_demand", "lora_demod_core_rollbacks"):
         getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = u64
     L.lora_demod_core_state.argtypes = [vp]; L.lora_demod_core_state.restype = i
+    L.lora_demod_core_rule_hits.argtypes = [vp, vp, f, sz, vp, i]; L.lora_demod_core_rule_hits.restype = sz
     L.lora_demod_core_last_error.argtypes = [vp]; L.lora_demod_core_last_error.restype = C.c_char_p
     L.lora_demod_core_reset.argtypes = [vp]; L.lora_demod_core_reset.restype = i
     L.lora_demod_core_preload.argtypes = [vp, u64, sz, vp, vp]; L.lora_demod_core_preload.restype = i

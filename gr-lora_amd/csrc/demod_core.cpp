@@ -1366,6 +1366,19 @@ int lora_demod_core_set_plan(lora_demod_core_t *c, int mode) {
   c->plan_mode = mode;
   return LORA_HIP_OK;
 }
+size_t lora_demod_core_rule_hits(const uint16_t *idx, const float *val, float threshold, size_t count, uint32_t *hits, int path) {
+  if (!idx || !val || !hits) return 0;
+  const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+  if (path == 2 && !have_avx2) return (size_t)-1;
+  if (path == 3) {
+    size_t nh = 0;
+    for (size_t j = 48; j < count; j++) if (rule_at(idx, val, threshold, j)) hits[nh++] = (uint32_t)j;
+    return nh;
+  }
+  if (path == 2 || (path == 0 && have_avx2)) return rule_hits_avx2(idx, val, threshold, count, hits);
+  return rule_hits_sse2(idx, val, threshold, count, hits);
+}
+
 uint64_t lora_demod_core_plans(const lora_demod_core_t *c) { return c ? c->n_plans : 0; }
 uint64_t lora_demod_core_replans(const lora_demod_core_t *c) { return c ? c->n_replans : 0; }
 uint64_t lora_demod_core_on_demand(const lora_demod_core_t *c) { return c ? c->n_demand : 0; }

@@ -109,6 +109,14 @@ LORA_HIP_API uint64_t lora_demod_core_on_demand(const lora_demod_core_t *c);
  * threshold than predicted: the block then resumes from the S_RESET call before that packet, evaluating on demand */
 LORA_HIP_API uint64_t lora_demod_core_rollbacks(const lora_demod_core_t *c);
 
+/* For tests: the preamble rule of :247-273 over a sweep of lattice results, as the planned block's SFD stage evaluates it
+ * (16-bit vector compares, squelch included): position j >= 48 is reported when the bins at j-16, j-32, j-48 -- the three
+ * older windows of j's lattice phase -- lie within LORA_PREAMBLE_TOLERANCE of the bin at j and val[j] > threshold.  hits
+ * must hold count entries; returns how many were written (ascending).  path: 0 = what the block uses on this CPU,
+ * 1 = the SSE2 form, 2 = the AVX2 + BMI2 form (returns (size_t)-1 when the CPU lacks them), 3 = the scalar definition. */
+LORA_HIP_API size_t lora_demod_core_rule_hits(const uint16_t *idx, const float *val, float threshold, size_t count,
+                                              uint32_t *hits, int path);
+
 /* Sharded replay of one long capture (no counterpart in the reference).  The block's state is determined
  * by its read index alone at every S_RESET call (:215-229 clears the rest) and at every S_DETECT_PREAMBLE call (the
  * argmax history then holds the four windows before the read index, :207-212, :233-242): two blocks that make such a call
