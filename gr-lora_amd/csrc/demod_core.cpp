@@ -1197,7 +1197,7 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   if (const char *e = getenv("LORA_CORE_FAULT")) c->fault_at = atol(e);
   if (const char *e = getenv("LORA_CORE_TIMING")) c->timing = atoi(e) != 0;
   if (const char *e = getenv("LORA_CORE_NO_FAST")) c->no_fast = atoi(e) != 0;
-  if (const char *e = getenv("LORA_CORE_STRETCH")) { const long v = atol(e); if (v >= 4096) c->stretch_min = (size_t)v; }
+  if (const char *e = getenv("LORA_CORE_STRETCH")) { const long v = atol(e); if (v >= 2 * (long)kStretchOverlap) c->stretch_min = (size_t)v; }
   if (const char *e = getenv("LORA_CORE_PLAN")) { const int m = atoi(e); if (m >= 0 && m <= 2) c->plan_mode = m; }
   c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor; c->div_f.set(fft_factor);
   c->d_num_symbols = 1u << sf;                                      // :79

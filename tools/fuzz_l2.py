@@ -5,6 +5,8 @@ the squelch threshold, amplitude scaling, and chunked feeding.  Uses the L2 bar 
 identical call sequence and PDUs, or a divergence that starts at a window whose top-2 margin is below 1e-4.
 
   python tools/fuzz_l2.py [seconds] [seed] [any]      # "any": draw fft_factor from ANY_FACTORS too
+  LORA_CORE_PLAN=2 LORA_CORE_STRETCH=2048 LORA_FUZZ_PACKETS=24 python tools/fuzz_l2.py 300 7
+                                                      # every input planned, in stretches of 128 symbols: the pipelined block
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +25,7 @@ def random_case(rng, factors=(1, 2, 2, 4)):
     f = int(rng.choice(list(factors)))
     ldr = int(rng.integers(0, 2))
     n = 1 << sf
-    n_pk = int(rng.integers(1, 5))
+    n_pk = int(rng.integers(1, 1 + int(os.environ.get("LORA_FUZZ_PACKETS", "4"))))     # more packets: inputs long enough for several stretches
     parts = []
     for k in range(n_pk):
         parts.append(np.zeros(int(rng.integers(0, 6 * n)), np.complex64))
