@@ -52,6 +52,7 @@ struct lora_hip_demod {
   void *d_desc1 = nullptr; size_t cap_desc1 = 0;
   unsigned char *d_runs1 = nullptr; size_t cap_runs1 = 0;
   unsigned char *d_out1 = nullptr, *h_out1 = nullptr; size_t cap_out1 = 0;
+  unsigned char *h_fetch = nullptr; size_t cap_fetch = 0;     // lora_hip_demod_fetch: page-locked landing block for small copies back
   // run lists of lora_hip_demod_batch_runs: page-locked staging per lane, copied to HBM behind the call (no synchronisation);
   // the event says when the lane's last copy is done with it
   // two blocks per lane, used in turn, so that a call waits for the copy of the call before the last, not for the last
@@ -489,6 +490,7 @@ void lora_hip_demod_destroy(lora_hip_demod_t *h) {
     if (h->marks[m]) (void)hipEventDestroy(h->marks[m]);
   (void)hipFree(h->d_ticket1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_runs1); (void)hipFree(h->d_out1);
   if (h->h_out1) (void)hipHostFree(h->h_out1);
+  if (h->h_fetch) (void)hipHostFree(h->h_fetch);
   if (h->scratch_slot >= 0 && h->device < kMaxDevices) {   // the slot goes back; the next owner clears it if this one left it undefined
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     g_scratch_used[h->device] &= ~(1u << h->scratch_slot);
@@ -542,7 +544,24 @@ int lora_hip_demod_fetch(lora_hip_demod_t *h, const lora_c32 *src_dev, size_t n,
   if (!n) return LORA_HIP_OK;
   DeviceGuard guard(h->device);
   HIP_TRY(h, guard.err);
-  HIP_TRY(h, hipMemcpyAsync(dst, src_dev, n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+  // A copy into pageable memory makes the runtime pin and unpin the destination (tens of microseconds for a few KiB); what
+  // the block fetches per work() call is the unconsumed tail, < 4N samples, so it lands in a page-locked block of the handle
+  const size_t bytes = n * sizeof(float2);
+  constexpr size_t kFetchMax = 1u << 20;
+  if (bytes <= kFetchMax) {
+    if (bytes > h->cap_fetch) {
+      if (h->h_fetch) { (void)hipHostFree(h->h_fetch); h->h_fetch = nullptr; h->cap_fetch = 0; }
+      const size_t ncap = bytes < 65536 ? 65536 : kFetchMax;
+      hipError_t e = hipHostMalloc((void **)&h->h_fetch, ncap, hipHostMallocDefault);
+      if (e != hipSuccess) { h->h_fetch = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+      h->cap_fetch = ncap;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->h_fetch, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(dst, h->h_fetch, bytes);
+    return LORA_HIP_OK;
+  }
+  HIP_TRY(h, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return LORA_HIP_OK;
 }
