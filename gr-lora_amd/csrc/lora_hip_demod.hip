@@ -131,6 +131,8 @@ Variant make_variant(const char *name) {
             lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN, F>(), lora_hip::block_threads(LOGN, F),
             lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name, 0, 0, 0, name};
   v.lds_const = v.lds; v.wpb_const = v.wpb; v.blocks_per_cu_const = v.blocks_per_cu;
+  // the list kernel keeps the chirp tables and the window in LDS where there is room (lora_hip::tap_lds)
+  if (lora_hip::tap_lds(LOGN, false, false)) v.lds = lora_hip::demod_tap_lds_offset<LOGN, F>() + lora_hip::demod_tap_lds_bytes<LOGN>();
   return v;
 }
 

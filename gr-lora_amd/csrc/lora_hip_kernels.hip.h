@@ -815,6 +815,26 @@ __device__ __forceinline__ WinCtx window_ctx(const KParams &p, const unsigned wi
   return c;
 }
 
+template <int LOGN, int F>
+constexpr size_t demod_lds_bytes() {
+  constexpr int kBlock = block_threads(LOGN, F);
+  constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
+  return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
+         2 * (kBlock / 64) * sizeof(Best) + 16 /* ticket ring */;
+}
+// The windows of a list (SFD searches, header/payload reads) each have their own chirp offset, so their taps are read per
+// window: 2 KiB per SF8 window through the vector-memory return path, the scarce one (with these loads compiled out the
+// SF8 SFD sweep runs 1.2x faster, profiles/r03_sfd_shared_tile_bound.txt).  Where the LDS has room (SF <= 8: 36 N bytes
+// per workgroup at three workgroups per CU) the list kernels keep both chirp tables and the window there instead.
+#ifndef LORA_TAP_LDS
+#define LORA_TAP_LDS 1
+#endif
+constexpr bool tap_lds(int logn, bool const_off, bool anyf) { return LORA_TAP_LDS && !const_off && !anyf && logn <= 8; }
+template <int LOGN>
+constexpr size_t demod_tap_lds_bytes() { return (size_t)(4 << LOGN) * sizeof(float2) + ((size_t)1 << LOGN) * sizeof(float); }
+template <int LOGN, int F>
+constexpr size_t demod_tap_lds_offset() { return (demod_lds_bytes<LOGN, F>() + 15) / 16 * 16; }
+
 // Persistent workgroups take groups of WPB windows from a global ticket counter.  The shares must be
 // dynamic: a SIMD issues VALU work for its waves in pairs, so with three resident workgroups per CU
 // one of them runs up to twice as fast as the other two in VALU-bound phases (measured: equal static
@@ -863,6 +883,16 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
       const float2 *__restrict__ g = reinterpret_cast<const float2 *>(p.twp[ps]);
       for (int i = tid; i < pass_entries(LOGN, F, ps); i += kBlock) lds_tw[pass_lds_offset(LOGN, F, ps) + i] = g[i];
     }
+  }
+
+  // list kernels at SF <= 8: both chirp tables and the window -> LDS (tap_lds above; visible after the barrier below)
+  constexpr bool kTapLds = tap_lds(LOGN, CONST_OFF, ANYF);
+  float2 *lds_up = reinterpret_cast<float2 *>(smem_raw + demod_tap_lds_offset<LOGN, F>());   // [2N], then down [2N], then window [N]
+  float2 *lds_down = lds_up + 2 * N;
+  float *lds_win = reinterpret_cast<float *>(lds_down + 2 * N);
+  if constexpr (kTapLds) {
+    for (int i = tid; i < 2 * N; i += kBlock) { lds_up[i] = p.up[i]; lds_down[i] = p.down[i]; }
+    for (int i = tid; i < N; i += kBlock) lds_win[i] = p.win[i];
   }
 
 #if LORA_CLOCK
@@ -1049,8 +1079,8 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #pragma unroll
       for (int k = 0; k < R; k++) { c[k] = cc[k]; if (LORA_REF_ROUNDING) cw[k] = cwin[k]; }
     } else {
-      const float2 *__restrict__ chirp = (cur.kind == 0 ? p.down : p.up) + cur.off + tw;
-      const float *__restrict__ wsrc = p.win + tw;
+      const float2 *__restrict__ chirp = (kTapLds ? (cur.kind == 0 ? lds_down : lds_up) : (cur.kind == 0 ? p.down : p.up)) + cur.off + tw;
+      const float *__restrict__ wsrc = (kTapLds ? lds_win : p.win) + tw;
 #pragma unroll
       for (int k = 0; k < R; k++) {
 #if LORA_ABL & 2
@@ -1250,13 +1280,6 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #endif
 }
 
-template <int LOGN, int F>
-constexpr size_t demod_lds_bytes() {
-  constexpr int kBlock = block_threads(LOGN, F);
-  constexpr int N = 1 << LOGN, T = N / plan_points(LOGN), WPB = kBlock / T, PADN = N + N / 16;
-  return (size_t)WPB * PADN * sizeof(float2) + (size_t)demod_lds_table_entries<LOGN, F>() * sizeof(float2) +
-         2 * (kBlock / 64) * sizeof(Best) + 16 /* ticket ring */;
-}
 template <int LOGN, int F>
 constexpr int demod_wpb() { return block_threads(LOGN, F) / ((1 << LOGN) / plan_points(LOGN)); }
 
