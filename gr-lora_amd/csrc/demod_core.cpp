@@ -666,30 +666,13 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user, bool overlap, Betw
   const uint64_t a_last = P.walk_end;
   int rc = LORA_HIP_OK;
   try {
-#ifdef LORA_CORE_PROFILE
-    uint64_t cyc[9] = {0}, cnt[9] = {0};
-#endif
     while (c->base + c->total() >= c->pos + need && c->pos <= a_last) {
-#ifdef LORA_CORE_PROFILE
-      const int st = c->d_state; const uint64_t tc0 = __rdtsc(), nc0 = c->n_calls;
-      if ((c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) && !c->no_fast && first_pass_reads(c, P, need, a_last)) {
-        cyc[8] += __rdtsc() - tc0; cnt[8] += c->n_calls - nc0; continue;
-      }
-#else
       if ((c->d_state == LORA_S_READ_HEADER || c->d_state == LORA_S_READ_PAYLOAD) && !c->no_fast && first_pass_reads(c, P, need, a_last)) continue;
-#endif
       unsigned consumed = 0;
       rc = general_work(c, nullptr, nullptr, &consumed);
-#ifdef LORA_CORE_PROFILE
-      cyc[st & 7] += __rdtsc() - tc0; cnt[st & 7]++;
-#endif
       if (rc) break;
       c->pos += consumed;
     }
-#ifdef LORA_CORE_PROFILE
-    for (int i = 0; i < 9; i++) if (cnt[i]) fprintf(stderr, "[core]     state %d%s: %llu calls, %llu cycles, %.1f per call\n", i, i == 8 ? " (short cut)" : "",
-                                                    (unsigned long long)cnt[i], (unsigned long long)cyc[i], (double)cyc[i] / cnt[i]);
-#endif
   } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   c->shadow = false; c->deferred = false;
   const double t_walked = now_s();
