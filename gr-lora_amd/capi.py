@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip_de
 OK, EINVAL, EUNSUPPORTED, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4, -5
 NOALLOC_MAX_HANDLES = 16      # include/lora_hip_demod.h: LORA_HIP_NOALLOC_MAX_HANDLES
 WIN_UP, WIN_SFD = 0, 1
-IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED, OUT_PINNED, NO_VAL, LANE1 = 1, 2, 4, 8, 16, 32, 64, 128
+IQ_ON_DEVICE, OUT_ON_DEVICE, DESC_ON_DEVICE, ASYNC, IQ_STAGED, OUT_PINNED, NO_VAL, LANE1, OUT_DIRECT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 WIN_DESC_DTYPE = np.dtype([("pos", "<u8"), ("chirp_off", "<u2"), ("kind", "u1"), ("reserved", "u1", (5,))])
 assert WIN_DESC_DTYPE.itemsize == 16

@@ -207,6 +207,7 @@ struct lora_demod_core : WalkState {
   bool collect = false;                                        // lora_demod_core_set_collect
   std::vector<uint16_t> col_syms; std::vector<uint64_t> col_off;
   long fault_at = -1; uint64_t n_pred = 0, n_rollbacks = 0;    // LORA_CORE_FAULT: test hook, mispredict that window
+  unsigned read_flags = LORA_HIP_OUT_DIRECT;      // LORA_CORE_READ_DIRECT=0: the READ stage's results through the copies (developer knob)
   bool no_fast = false;          // LORA_CORE_NO_FAST=1: every call of the first pass through general_work (tests compare the two)
   uint64_t n_plans = 0, n_replans = 0, n_demand = 0;
   // LORA_CORE_TIMING=1: seconds per stage of the last work() call on stderr (lattice sweep, SFD scan, SFD launch, dry
@@ -692,7 +693,7 @@ int plan_walk(lora_demod_core *c, lora_pdu_cb cb, void *user, bool overlap, Betw
   for (PRun &r : P.rd) all.push_back(&r);
   const double t1 = now_s();
   // the READ stage's round trip (run list to HBM, launch, results back: ~60 us) passes while the host does `between`
-  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane | (overlap ? (unsigned)LORA_HIP_ASYNC : 0u));
+  rc = launch_planned(c, all, LORA_WIN_UP, P.r_idx, &P.r_val, c->walk_lane | (overlap ? (unsigned)LORA_HIP_ASYNC : 0u) | c->read_flags);
   const double t1b = now_s();
   double t_between = 0, t_rsync = 0;
   if (overlap) {
@@ -1180,6 +1181,7 @@ int lora_demod_core_create(lora_demod_core_t **out, int device, unsigned sf, int
   if (const char *e = getenv("LORA_CORE_FAULT")) c->fault_at = atol(e);
   if (const char *e = getenv("LORA_CORE_TIMING")) c->timing = atoi(e) != 0;
   if (const char *e = getenv("LORA_CORE_NO_FAST")) c->no_fast = atoi(e) != 0;
+  if (const char *e = getenv("LORA_CORE_READ_DIRECT")) c->read_flags = atoi(e) ? (unsigned)LORA_HIP_OUT_DIRECT : 0u;
   if (const char *e = getenv("LORA_CORE_STRETCH")) { const long v = atol(e); if (v >= 2 * (long)kStretchOverlap) c->stretch_min = (size_t)v; }
   if (const char *e = getenv("LORA_CORE_PLAN")) { const int m = atoi(e); if (m >= 0 && m <= 2) c->plan_mode = m; }
   c->d_sf = sf; c->d_ldr = ldr != 0; c->d_beta = beta; c->d_fft_size_factor = fft_factor; c->div_f.set(fft_factor);

@@ -627,7 +627,11 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
     }
   } else p.desc = nullptr;
   // outputs
-  if (out_dev) { p.out_idx = max_idx; p.out_val = max_val; }
+  // LORA_HIP_OUT_DIRECT: the kernel stores its results into the caller's page-locked arrays itself (they are mapped into the
+  // device's address space; the stores are visible to the host once the lane has been synchronised): two copy operations
+  // fewer behind a small launch, for which their dispatch, not their size, is what takes time
+  const bool out_direct = out_pinned && (flags & LORA_HIP_OUT_DIRECT) && !no_val;
+  if (out_dev || out_direct) { p.out_idx = max_idx; p.out_val = max_val; }
   else {
     if (n_win > cap_out) {
       // (hipFree waits for the device: a launch still reading the old block on this lane is done before it goes)
@@ -648,6 +652,10 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
   p.n_win = (unsigned)n_win;
   if ((rc = launch(h, p, true, lane)) != LORA_HIP_OK) return rc;
+  if (out_direct) {
+    if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(stream));
+    return LORA_HIP_OK;
+  }
   if (!out_dev) {
     const size_t idx_off = n_win * 4;
     if (out_pinned) {

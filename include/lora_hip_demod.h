@@ -60,6 +60,9 @@ enum {
                                    are copied straight into them instead of through the handle's own pinned mirror */
   LORA_HIP_NO_VAL = 64,         /* max_val may be NULL and is not written (host outputs only): half the copy back
                                    for callers that need the bins only, like the SFD search (demod_impl.cc:322) */
+  LORA_HIP_OUT_DIRECT = 256,    /* with LORA_HIP_OUT_PINNED: the kernel writes the results into the page-locked arrays itself
+                                   instead of into the handle's device block with two copies behind it; for small launches,
+                                   where the copies' dispatch is what takes time (a large one is faster through the copies) */
   LORA_HIP_LANE1 = 128          /* run on the handle's second lane: a stream of the handle's own with its own counters and
                                    staging, so that a small launch (a block's header/payload windows, :363-413) overtakes
                                    the long sweeps queued on the first lane.  Samples must be staged or on the device.

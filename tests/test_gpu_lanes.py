@@ -64,6 +64,18 @@ def test_queued_sweeps_marks_and_the_second_lane(g):
             assert L.lora_hip_demod_wait(h._h, 1) == 0
             assert np.array_equal(bufs[1].idx, ref[1][0]) and bufs[1].val.tobytes() == ref[1][1].tobytes()
             assert L.lora_hip_demod_sync(h._h, 0) == 0
+        # LORA_HIP_OUT_DIRECT: the kernel stores into the page-locked arrays itself; same bits, synchronous and queued, either lane
+        for extra in (0, capi.LANE1):
+            for b in bufs:
+                b.idx[:] = 0xFFFF; b.val[:] = -7
+            p0, st, cnt, off, step, kind = sweeps[2]
+            assert L.lora_hip_demod_batch_strided(h._h, None, len(iq), p0, st, cnt, off, step, kind, bufs[2].pi, bufs[2].pv,
+                                                  capi.OUT_PINNED | capi.IQ_STAGED | capi.OUT_DIRECT | extra) == 0
+            assert np.array_equal(bufs[2].idx, ref[2][0]) and bufs[2].val.tobytes() == ref[2][1].tobytes()
+            assert queue(1, capi.OUT_DIRECT | extra) == 0 and queue(0, capi.OUT_DIRECT | extra) == 0
+            assert L.lora_hip_demod_sync(h._h, 1 if extra else 0) == 0
+            for k in (0, 1):
+                assert np.array_equal(bufs[k].idx, ref[k][0]) and bufs[k].val.tobytes() == ref[k][1].tobytes()
         # a mark that was never set counts as reached; bad lanes and marks are refused
         assert L.lora_hip_demod_wait(h._h, 7) == 0
         assert L.lora_hip_demod_wait(h._h, 8) == capi.EINVAL and L.lora_hip_demod_mark(h._h, 0, -1) == capi.EINVAL
