@@ -193,7 +193,7 @@ struct lora_demod_core : WalkState {
   // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs its launches, a READ round
   // trip that nothing hides (~0.06 ms, more when the READ launch has to wait for a running sweep to let go of the CUs) and the
   // state machine's wait for its SFD stage; measured on 524 k positions (8.4 M samples at SF8, 386 packets,
-  // profiles/r03_pipeline.txt): 1 stretch 1.56 ms, 2 stretches 1.34, 3 stretches 1.36-1.42, 4 stretches 1.51, 7 stretches 1.57
+  // profiles/r03_pipeline.txt, end of round 3): 1 stretch 1.40 ms, 2 stretches 1.16, 3 stretches 1.19, 4 stretches 1.24, 7 stretches 1.46
   size_t stretch_min = 180000;
   bool shadow = false;           // dry run: no launches, no PDUs, misses are predicted and recorded in `needs`
   std::vector<PRun> needs;
