@@ -189,6 +189,7 @@ struct lora_demod_core : WalkState {
   // already evaluates the SFD stage of the next and the lattice sweep of the one after (pipeline_run)
   Plan plans[kPlans]; Plan *planp = &plans[0]; int plan_mode = 1;
   Plan &cur() { return *planp; }
+  uint64_t dens_pdus = 0, dens_syms = 0;    // traffic of the last calls (halved every 4096 symbols): PDUs emitted, symbols consumed
   unsigned walk_lane = 0;        // LORA_HIP_LANE1 while stretches are in flight: what the walk launches must not queue behind them
   // Lattice positions per stretch at least (LORA_CORE_STRETCH: developer knob).  A stretch costs its launches, a READ round
   // trip that nothing hides (~0.06 ms, more when the READ launch has to wait for a running sweep to let go of the CUs) and the
@@ -318,6 +319,10 @@ constexpr int kShadowStop = 1;                    // dry run met something it ca
 // lattice windows; on demand a packet costs two to four launches.  Measured on configs[3] (one packet per 280-symbol
 // capture, four blocks in flight): 0.19 s planned against 0.12 s on demand, so the plan starts where several packets fit.
 constexpr size_t kPlanMinSymbols = 1024;
+// ... unless the stream has been dense lately: with a packet per kDenseSymbols symbols or more over the last calls a plan
+// repays itself from kPlanMinDense symbols on (SF8 in 256-symbol chunks of back-to-back packets: 162 us planned against 275 us
+// on demand per call, profiles/r03_stream.txt; one packet per 276-symbol capture, configs[3]: 0.15 s on demand against 0.22)
+constexpr size_t kPlanMinDense = 192, kDenseSymbols = 160;
 constexpr size_t kPlanMaxSfd = (size_t)1 << 23;   // SFD windows per plan
 constexpr unsigned kMaxReplans = 16;
 constexpr unsigned kSfdSpan = 9 * OVERLAP_FACTOR + 1;   // :283-292: nine full calls, then the call that gives up evaluates one
@@ -822,7 +827,8 @@ int pipeline_run(lora_demod_core *c, lora_pdu_cb cb, void *user) {
   const uint64_t need = (uint64_t)n + (uint64_t)DEMOD_HISTORY_DEPTH * n - 1;
   if (end < c->pos + need) return LORA_HIP_OK;
   const size_t total = (size_t)((end - c->pos - n) / step + 1);
-  if (c->plan_mode == 1 && total < kPlanMinSymbols * OVERLAP_FACTOR) return LORA_HIP_OK;
+  const bool dense = c->dens_pdus > 0 && c->dens_pdus * kDenseSymbols >= c->dens_syms;
+  if (c->plan_mode == 1 && total < (dense ? kPlanMinDense : kPlanMinSymbols) * OVERLAP_FACTOR) return LORA_HIP_OK;
   size_t K = total / c->stretch_min;
   if (K < 1) K = 1;
   if (K > kMaxStretches) K = kMaxStretches;
@@ -1205,6 +1211,7 @@ int lora_demod_core_reset(lora_demod_core_t *c) {
   c->buf.assign((size_t)DEMOD_HISTORY_DEPTH * c->d_num_symbols - 1, lora_c32{0.f, 0.f});
   c->cur_in = nullptr; c->cur_n = 0;
   c->base = 0; c->pos = 0; c->n_pdus = 0;
+  c->dens_pdus = 0; c->dens_syms = 0;
   c->idle.clear(); c->idle_calls0.clear();
   c->up_runs.clear(); c->pre_runs.clear(); c->sfd_runs.clear();
   for (unsigned &m : c->sfd_misses) m = 0;
@@ -1266,6 +1273,7 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
   for (double &t : c->t_stage) t = 0;
   c->t_cb = 0; c->t_wait = 0; c->t_real = 0;
   const double t_begin = now_s();
+  const uint64_t pdus0 = c->n_pdus, pos0 = c->pos;
   try { rc = pipeline_run(c, cb, user); } catch (const std::bad_alloc &) { rc = LORA_HIP_ENOMEM; }
   const double t_walk = now_s();
   while (!rc && c->base + c->total() >= c->pos + need) {
@@ -1284,6 +1292,8 @@ static int core_work(lora_demod_core_t *c, const lora_c32 *in, size_t n_in, bool
             c->t_stage[2] * 1e3, c->t_stage[3] * 1e3, c->t_stage[4] * 1e3, (c->t_stage[5] - c->t_cb) * 1e3, c->t_cb * 1e3, (t_end - t_begin) * 1e3,
             (unsigned long long)c->n_launches);
   }
+  c->dens_pdus += c->n_pdus - pdus0; c->dens_syms += (c->pos - pos0) / c->d_num_symbols;
+  if (c->dens_syms > 4096) { c->dens_pdus /= 2; c->dens_syms /= 2; }
   // keep what can still be read, [pos, end), as the next call's carry; cached runs keep absolute positions
   try {
     const uint64_t carry_end = c->base + c->buf.size();

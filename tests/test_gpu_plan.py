@@ -223,3 +223,25 @@ def test_pinned_results_and_bins_only(g):
     finally:
         L.lora_hip_host_free(pi); L.lora_hip_host_free(pv)
         h.close()
+
+
+def test_dense_stream_in_short_chunks_switches_to_plans(g):
+    """Default mode plans an input of at least 1024 symbols -- or of 192 when the stream has carried a packet per 160 symbols or more
+    lately (demod_core.cpp: kPlanMinDense).  A dense stream fed in 256-symbol chunks: the first chunk is evaluated on demand, later
+    ones are planned; a sparse one (a packet per ~400 symbols) never is.  Either way the trace is the on-demand block's."""
+    sf, f = 7, 2
+    n = 1 << sf
+    cap = dense_capture(sf, 40, seed=77, max_gap=6)
+    chunk = 256 * n
+    pieces = [cap[k:k + chunk] for k in range(0, len(cap), chunk)]
+    assert len(pieces) >= 6
+    want, tr_w, st_w = run_block(g, sf, f, 0, pieces, plan=0)
+    got, tr_g, st_g = run_block(g, sf, f, 0, pieces, plan=1)
+    assert st_w["plans"] == 0 and st_g["plans"] >= len(pieces) - 3, (st_w, st_g)
+    assert same_pdus(want, got) and len(got) >= 20 and tr_w.tobytes() == tr_g.tobytes()
+    assert st_g["launches"] < st_w["launches"]
+    sparse = dense_capture(sf, 6, seed=78, max_gap=700)
+    pieces = [sparse[k:k + chunk] for k in range(0, len(sparse), chunk)]
+    got, tr_g, st_g = run_block(g, sf, f, 0, pieces, plan=1)
+    want, tr_w, st_w = run_block(g, sf, f, 0, pieces, plan=0)
+    assert st_g["plans"] == 0 and same_pdus(want, got) and tr_w.tobytes() == tr_g.tobytes()
