@@ -43,7 +43,10 @@ def random_case(rng, factors=(1, 2, 2, 4)):
     elif mode < 0.8:
         cap = (cap * np.float32(rng.uniform(0.001, 3.0))).astype(np.complex64)
     chunks = None
-    if rng.random() < 0.4:
+    big = int(os.environ.get("LORA_FUZZ_CHUNK_SYMS", "0"))        # > 0: chunks of up to this many symbols (default-mode planning of
+    if big and rng.random() < 0.7:                                # dense streams sets in at 192 symbols per call)
+        chunks = [int(c) for c in rng.integers(64 * n, big * n, int(rng.integers(1, 30)))]
+    elif rng.random() < 0.4:
         chunks = [int(c) for c in rng.integers(1, 3 * n, int(rng.integers(1, 30)))]
     return sf, f, ldr, cap, chunks
 
