@@ -115,6 +115,10 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
   return LORA_HIP_OK;
 }
 
+#ifndef LORA_NO_MIRROR_DIRECT
+#define LORA_NO_MIRROR_DIRECT 0   // developer knob: 1 = small host-output calls go through the device block and a copy, as before
+#endif
+constexpr size_t kMirrorDirectMax = 8192;   // windows
 #ifndef LORA_NO_CONST
 #define LORA_NO_CONST 0   // developer knob: 1 = never use the register-resident-taps variant
 #endif
@@ -631,6 +635,7 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
   // device's address space; the stores are visible to the host once the lane has been synchronised): two copy operations
   // fewer behind a small launch, for which their dispatch, not their size, is what takes time
   const bool out_direct = out_pinned && (flags & LORA_HIP_OUT_DIRECT) && !no_val;
+  bool mirror_direct = false;
   if (out_dev || out_direct) { p.out_idx = max_idx; p.out_val = max_val; }
   else {
     if (n_win > cap_out) {
@@ -647,6 +652,13 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
     }
     p.out_val = reinterpret_cast<float *>(d_out);
     p.out_idx = reinterpret_cast<unsigned short *>(d_out + n_win * 4);     // packed behind this call's values
+    // a small synchronous call with pageable results (the block's on-demand launches): the kernel stores straight into the
+    // handle's page-locked mirror, which saves the copy operation between the kernel and the synchronisation
+    mirror_direct = !out_pinned && !(flags & LORA_HIP_ASYNC) && n_win <= kMirrorDirectMax && !LORA_NO_MIRROR_DIRECT;
+    if (mirror_direct) {
+      p.out_val = reinterpret_cast<float *>(h_out);
+      p.out_idx = reinterpret_cast<unsigned short *>(h_out + n_win * 4);
+    }
   }
   p.up = h->d_up; p.down = h->d_down; p.win = h->d_win;
   for (int ps = 0; ps < 4; ps++) p.twp[ps] = h->d_tw + h->tw_off[ps];
@@ -666,7 +678,8 @@ static int run_batch(lora_hip_demod_t *h, const lora_c32 *iq, size_t n_samples, 
       if (!(flags & LORA_HIP_ASYNC)) HIP_TRY(h, hipStreamSynchronize(stream));
       return LORA_HIP_OK;
     }
-    if (no_val) HIP_TRY(h, hipMemcpyAsync(h_out + idx_off, d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, stream));
+    if (mirror_direct) {}
+    else if (no_val) HIP_TRY(h, hipMemcpyAsync(h_out + idx_off, d_out + idx_off, n_win * 2, hipMemcpyDeviceToHost, stream));
     else HIP_TRY(h, hipMemcpyAsync(h_out, d_out, n_win * 6, hipMemcpyDeviceToHost, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
     if (!no_val) memcpy(max_val, h_out, n_win * 4);
