@@ -115,6 +115,9 @@ int grow(lora_hip_demod *h, T **buf, size_t *cap, size_t want) {
   return LORA_HIP_OK;
 }
 
+#ifndef LORA_NO_BOUNCE
+#define LORA_NO_BOUNCE 0   // developer knob: 1 = small pageable copies are left to the runtime, as before
+#endif
 #ifndef LORA_NO_MIRROR_DIRECT
 #define LORA_NO_MIRROR_DIRECT 0   // developer knob: 1 = small host-output calls go through the device block and a copy, as before
 #endif
@@ -515,6 +518,21 @@ int lora_hip_demod_set_stream(lora_hip_demod_t *h, void *hip_stream) {
   return LORA_HIP_OK;
 }
 
+// Small copies between pageable host memory and the device go through one page-locked block of the handle: left to the
+// runtime, a pageable copy of a few hundred KiB pins and unpins the caller's pages, and what that costs varied between 10 and
+// several hundred microseconds from process to process (profiles/r03_stream.txt: the same 128 KiB chunks at 100 or 550 us
+// per call).  All users are synchronous, so one block serves them.
+constexpr size_t kBounceMax = 1u << 20;
+static int bounce(lora_hip_demod_t *h, size_t bytes) {
+  if (bytes <= h->cap_fetch) return LORA_HIP_OK;
+  if (h->h_fetch) { (void)hipHostFree(h->h_fetch); h->h_fetch = nullptr; h->cap_fetch = 0; }
+  const size_t ncap = bytes < 65536 ? 65536 : kBounceMax;
+  hipError_t e = hipHostMalloc((void **)&h->h_fetch, ncap, hipHostMallocDefault);
+  if (e != hipSuccess) { h->h_fetch = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
+  h->cap_fetch = ncap;
+  return LORA_HIP_OK;
+}
+
 int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a, const lora_c32 *b, size_t n_b) {
   if (!h || (!a && n_a) || (!b && n_b)) return LORA_HIP_EINVAL;
   DeviceGuard guard(h->device);
@@ -523,8 +541,15 @@ int lora_hip_demod_stage_iq2(lora_hip_demod_t *h, const lora_c32 *a, size_t n_a,
   const size_t n = n_a + n_b;
   int rc = grow(h, &h->d_iq, &h->cap_iq, n ? n : 1);
   if (rc != LORA_HIP_OK) return rc;
-  if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  if (n_b) HIP_TRY(h, hipMemcpyAsync(h->d_iq + n_a, b, n_b * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (n && n * sizeof(float2) <= kBounceMax && !LORA_NO_BOUNCE) {
+    if ((rc = bounce(h, n * sizeof(float2))) != LORA_HIP_OK) return rc;
+    if (n_a) memcpy(h->h_fetch, a, n_a * sizeof(float2));
+    if (n_b) memcpy(h->h_fetch + n_a * sizeof(float2), b, n_b * sizeof(float2));
+    HIP_TRY(h, hipMemcpyAsync(h->d_iq, h->h_fetch, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  } else {
+    if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    if (n_b) HIP_TRY(h, hipMemcpyAsync(h->d_iq + n_a, b, n_b * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));     // the host buffers may be reused by the caller
   h->staged_n = n;
   return LORA_HIP_OK;
@@ -538,7 +563,11 @@ int lora_hip_demod_stage_iq2_dev(lora_hip_demod_t *h, const lora_c32 *a, size_t 
   const size_t n = n_a + n_b;
   int rc = grow(h, &h->d_iq, &h->cap_iq, n ? n : 1);
   if (rc != LORA_HIP_OK) return rc;
-  if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (n_a && n_a * sizeof(float2) <= kBounceMax && !LORA_NO_BOUNCE) {
+    if ((rc = bounce(h, n_a * sizeof(float2))) != LORA_HIP_OK) return rc;
+    memcpy(h->h_fetch, a, n_a * sizeof(float2));
+    HIP_TRY(h, hipMemcpyAsync(h->d_iq, h->h_fetch, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  } else if (n_a) HIP_TRY(h, hipMemcpyAsync(h->d_iq, a, n_a * sizeof(float2), hipMemcpyHostToDevice, h->stream));
   if (n_b) HIP_TRY(h, hipMemcpyAsync(h->d_iq + n_a, b_dev, n_b * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->staged_n = n;
@@ -553,15 +582,9 @@ int lora_hip_demod_fetch(lora_hip_demod_t *h, const lora_c32 *src_dev, size_t n,
   // A copy into pageable memory makes the runtime pin and unpin the destination (tens of microseconds for a few KiB); what
   // the block fetches per work() call is the unconsumed tail, < 4N samples, so it lands in a page-locked block of the handle
   const size_t bytes = n * sizeof(float2);
-  constexpr size_t kFetchMax = 1u << 20;
-  if (bytes <= kFetchMax) {
-    if (bytes > h->cap_fetch) {
-      if (h->h_fetch) { (void)hipHostFree(h->h_fetch); h->h_fetch = nullptr; h->cap_fetch = 0; }
-      const size_t ncap = bytes < 65536 ? 65536 : kFetchMax;
-      hipError_t e = hipHostMalloc((void **)&h->h_fetch, ncap, hipHostMallocDefault);
-      if (e != hipSuccess) { h->h_fetch = nullptr; hip_fail(h, e, "hipHostMalloc"); return LORA_HIP_ENOMEM; }
-      h->cap_fetch = ncap;
-    }
+  if (bytes <= kBounceMax) {
+    const int rb = bounce(h, bytes);
+    if (rb != LORA_HIP_OK) return rb;
     HIP_TRY(h, hipMemcpyAsync(h->h_fetch, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     memcpy(dst, h->h_fetch, bytes);
