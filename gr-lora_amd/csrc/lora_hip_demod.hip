@@ -130,6 +130,7 @@ typedef void (*kernel_fn)(const KParams);
 struct Variant {
   kernel_fn fn, fn_const; size_t lds; int wpb, threads, blocks_per_cu; const char *name;
   size_t lds_const; int wpb_const, blocks_per_cu_const; const char *name_const;
+  kernel_fn fn_const_nt = nullptr;     // fn_const with non-temporal IQ loads, for sweeps whose windows do not overlap (SF >= 8)
 };
 
 template <int LOGN, int F>
@@ -138,6 +139,8 @@ Variant make_variant(const char *name) {
             lora_hip::demod_lds_bytes<LOGN, F>(), lora_hip::demod_wpb<LOGN, F>(), lora_hip::block_threads(LOGN, F),
             lora_hip::min_waves(LOGN, F) * 4 / (lora_hip::block_threads(LOGN, F) / 64), name, 0, 0, 0, name};
   v.lds_const = v.lds; v.wpb_const = v.wpb; v.blocks_per_cu_const = v.blocks_per_cu;
+  // measured +1.7 ... +5 % from SF8 up (profiles/r03_ab_nt_loads.txt), -0.8 % at SF7
+  if constexpr (LORA_PF_NT && LOGN >= 8) v.fn_const_nt = &lora_hip::demod_kernel<LOGN, F, true, false, true>;
   // the list kernel keeps the chirp tables and the window in LDS where there is room (lora_hip::tap_lds)
   if (lora_hip::tap_lds(LOGN, false, false)) v.lds = lora_hip::demod_tap_lds_offset<LOGN, F>() + lora_hip::demod_tap_lds_bytes<LOGN>();
   return v;
@@ -248,7 +251,8 @@ int launch(lora_hip_demod *h, KParams &p, const bool own_ticket, const int lane 
   }
   p.ticket = ticket;
   p.twist = h->d_twist; p.fr = h->fft_factor;
-  hipLaunchKernelGGL(const_off ? v.fn_const : v.fn, dim3(blocks), dim3(v.threads), lds, stream, p);
+  const kernel_fn fn = !const_off ? v.fn : (v.fn_const_nt && p.stride >= h->n) ? v.fn_const_nt : v.fn_const;
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(v.threads), lds, stream, p);
 #if LORA_STAMPS
   {
     std::vector<unsigned long long> hd(ndbg);
@@ -478,7 +482,8 @@ int lora_hip_demod_create(lora_hip_demod_t **out, int device, unsigned sf, unsig
   // kernels with more dynamic LDS than the runtime's default limit need the opt-in
   if (v.lds > 48 * 1024 || v.lds_const > 48 * 1024) {
     if (hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_const) != hipSuccess)
+        hipFuncSetAttribute((const void *)v.fn_const, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_const) != hipSuccess ||
+        (v.fn_const_nt && hipFuncSetAttribute((const void *)v.fn_const_nt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds_const) != hipSuccess))
       return fail(LORA_HIP_EHIP);
   }
   *out = h;

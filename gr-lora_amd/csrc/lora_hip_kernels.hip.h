@@ -21,11 +21,24 @@
 
 namespace lora_hip {
 
+#ifndef LORA_PF_NT
+#define LORA_PF_NT 1    // sweeps of stride >= N (SF >= 8) run the instantiation whose IQ loads carry the non-temporal hint (0: never)
+#endif
 // buffer_load_dwordx2 through the LLVM intrinsic (the clang builtin of this toolchain narrows b64 loads to one dword):
 // descriptor in four SGPRs, per-lane byte offset in one VGPR, a scalar byte offset per load
 typedef int buf_rsrc_t __attribute__((ext_vector_type(4)));
 typedef float buf_v2f_t __attribute__((ext_vector_type(2)));
 __device__ buf_v2f_t buffer_load_v2f32(buf_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+// one IQ sample; NT: with the non-temporal hint (a sample of a sweep whose windows do not overlap is read once)
+template <bool NT>
+__device__ __forceinline__ float2 iq_load(const float2 *p) {
+  if constexpr (NT) {
+    const buf_v2f_t t = __builtin_nontemporal_load(reinterpret_cast<const buf_v2f_t *>(p));
+    return make_float2(t.x, t.y);
+  } else {
+    return *p;
+  }
+}
 
 struct KParams {
   const float2 *iq;             // capture (device)
@@ -855,7 +868,8 @@ constexpr size_t demod_tap_lds_offset() { return (demod_lds_bytes<LOGN, F>() + 1
 // tables of F = 1 and a run-time number of sub-transforms p.fr.  Sub-transform rr gets the whole twist
 // x[n] * W_M^(rr*n) at its input, one complex multiply per sample by a table value that L2 keeps
 // (rr*n < M, so the table index needs no reduction), and then runs the plain N-point transform.
-template <int LOGN, int F, bool CONST_OFF, bool ANYF = false>
+// NT: the sweep's IQ loads carry the non-temporal hint (only launched when no window overlaps another)
+template <int LOGN, int F, bool CONST_OFF, bool ANYF = false, bool NT = false>
 __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void demod_kernel(const KParams p) {
   static_assert(!ANYF || F == 1, "the any-factor kernel is built on the F = 1 geometry");
   constexpr int kBlock = block_threads(LOGN, F);
@@ -1058,7 +1072,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
   {
     const float2 *__restrict__ src = p.iq + cur.pos + tw;
 #pragma unroll
-    for (int k = 0; k < R; k++) nx[k] = src[k * T];
+    for (int k = 0; k < R; k++) nx[k] = iq_load<NT>(&src[k * T]);
   }
   // The store of window i is deferred into window i + 1 when the window spans several waves (the partials
   // meet behind the next window's barriers) and, measured, whenever F > 1; at F = 1 with a window inside one
@@ -1169,7 +1183,7 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
 #if LORA_ABL & 1
             nx[k] = make_float2(1.0f + tw, k);
 #else
-            nx[k] = src[k * T];
+            nx[k] = iq_load<NT>(&src[k * T]);
 #endif
           }
         }
@@ -1193,7 +1207,11 @@ __global__ __launch_bounds__(block_threads(LOGN, F), min_waves(LOGN, F)) void de
             LORA_SCHED_FENCE();
 #pragma unroll
             for (int k = (R / kPfGroups) * g; k < (R / kPfGroups) * (g + 1); k++) {
-              const buf_v2f_t d = buffer_load_v2f32(pf_rsrc, tw * (int)sizeof(float2), k * T * (int)sizeof(float2), 0);
+              // cache policy 2 = nt: a sample of a stride >= N sweep is read once, and streaming it past the L2's retention is
+              // worth +1.5 % at F=2 and +2.5 % at F=1 (profiles/r03_ab_nt_loads.txt); an overlapped sweep (the block's lattice,
+              // stride N/16) lives on L2 hits and loses 11-15 % with the hint, and choosing at run time inside one kernel costs
+              // more than the hint gives: hence two instantiations, picked by the host from the stride
+              const buf_v2f_t d = buffer_load_v2f32(pf_rsrc, tw * (int)sizeof(float2), k * T * (int)sizeof(float2), NT ? 2 : 0);
               nx[k] = make_float2(d.x, d.y);
             }
             LORA_SCHED_FENCE();

@@ -33,10 +33,10 @@ def demangle(names):
     """demod_kernelILi12ELi2ELb1ELb0EE -> demod_kernel<12, 2, true, false>; other kernels: the name between the length prefixes"""
     out = []
     for n in names:
-        m = re.search(r"demod_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])EE", n)
+        m = re.search(r"demod_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])E(?:Lb([01])E)?E", n)
         if m:
             b = ("false", "true")
-            out.append(f"demod_kernel<{m.group(1)}, {m.group(2)}, {b[int(m.group(3))]}, {b[int(m.group(4))]}>")
+            out.append(f"demod_kernel<{m.group(1)}, {m.group(2)}, {b[int(m.group(3))]}, {b[int(m.group(4))]}>" + (" nt" if m.group(5) == "1" else ""))
         else:
             k = re.findall(r"\d+([a-z_][a-z_0-9]*kernel[a-z_0-9]*)", n)
             out.append(k[0] if k else n)
@@ -52,7 +52,7 @@ def main():
         m = re.search(r"demod_kernel<(\d+), (\d+), (true|false), (true|false)>", n)
         if m:
             sf, f, co, af = m.groups()
-            short = "demod_kernel"
+            short = "demod_kernel" + (" (nt loads)" if n.endswith(" nt") else "")
         else:
             sf = f = co = af = ""
             short = re.sub(r"\(.*", "", n).replace("void ", "").replace("(anonymous namespace)::", "")
