@@ -233,7 +233,16 @@ def main():
         # The data path has no collective (captures are independent): the process group only carries
         # the timing barrier and the max-over-ranks of two floats, so gloo on the host is enough and
         # RCCL/xGMI stay idle by design.
-        dist.init_process_group("gloo")
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     if args.dry_run:
         if world > 1:
             dist.barrier()

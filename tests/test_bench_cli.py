@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _json_line(out):
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out
+    # stdout is the one JSON line and nothing else (gloo's "[Gloo] Rank 0 is connected ..." goes to stderr)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out
     return json.loads(lines[0])
 
 
@@ -42,4 +43,4 @@ def test_under_a_launcher_each_process_is_one_rank():
             p.wait()
     assert all(p.returncode == 0 for p in procs), outs
     assert _json_line(outs[0][0])["n_gpus"] == 2
-    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # only rank 0 prints
+    assert not outs[1][0].strip()                                                # only rank 0 prints
